@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""
+bench.py -- sites/sec of the arbplf-ll hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full pass of the ll path over the rank's resident site
+patterns: exp(Q r t) for every (category, edge) (K1), traversal-program
+matrix stream + tip tables, the pruning kernel over all sites with category
+mixing and log (K2+K3), the weighted site reduction (K7) and, for N > 1, one
+RCCL all-reduce of the double-double log-likelihood sum (X1).  Pattern codes
+are resident in HBM before the timed region.
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+Sites are sharded by contiguous blocks, one process per GPU, weak scaling
+(every rank holds --sites patterns of the same synthetic alignment).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+FP64_PEAK = 78.6e12        # flop/s, fp64 vector = fp64 matrix dense peak
+
+
+def cpu_baseline(workload, sample_sites, seconds=15.0):
+    """Oracle 'port' (oracle/plf_core.c, double build, OpenMP) on host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import arbplf_oracle as O
+    O.build()
+    codes0 = workload.simulate(256)
+    md = workload.json_model(codes0[:, :1])
+    m = O.parse_model(md)
+    w = O.prepare(m)
+    # calibrate
+    probe = min(sample_sites, 2000)
+    codes = np.ascontiguousarray(workload.simulate(probe).T)
+    t0 = time.perf_counter()
+    O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(sample_sites, max(probe, probe * seconds / dt)))
+    n = max(256, n // 256 * 256)
+    codes = np.ascontiguousarray(workload.simulate(n).T)
+    t0 = time.perf_counter()
+    ll, used = O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="sites/s", cores=int(used), kind="port",
+                sample="first %d sites of the same synthetic alignment, double-precision oracle port, %d OpenMP threads, %.1f s"
+                       % (n, used, dt)), ll
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (2..5)")
+    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the config's S)")
+    ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from phyly_amd import synth
+    from phyly_amd import engine as E
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    wl = synth.Workload(args.config)
+    S = args.sites or wl.default_S
+    eng = E.Engine(local_rank)
+    wl.setup_engine(eng)
+    if args.kernel == "generic":
+        eng.set_option(E.OPT_FORCE_GENERIC, 1)
+
+    # resident patterns: this rank's block of the alignment, generated on the GPU
+    chunk = 1 << 20
+    codes = torch.empty((wl.N, S), dtype=torch.uint8, device=dev)
+    for off in range(0, S, chunk):
+        n = min(chunk, S - off)
+        codes[:, off:off + n] = wl.simulate(n, site0=rank * S + off, device=dev)
+    torch.cuda.synchronize()
+    eng.set_patterns_codes(codes.data_ptr(), wl.defs, S=S, where=E.DEVICE)
+    del codes
+    torch.cuda.empty_cache()
+
+    red = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def step():
+        eng.update_edge_rates(wl.edge_rates_csr)       # forces K1 + stream + tips
+        _, (hi, lo) = eng.ll(per_site=False, want_sum=True)
+        if world > 1:
+            red[0], red[1] = hi, lo
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            hi, lo = red.tolist()
+        return hi + lo
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    total = None
+    for _ in range(args.warmup):
+        total = step()
+    kern_ns = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+        kern_ns.append(eng.info(E.INFO_LL_KERNEL_NS))
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        alg = wl.algorithmic()
+        kernel_kind = eng.info(E.INFO_LL_KERNEL)
+        kern_s = float(np.mean(kern_ns)) * 1e-9
+        value = world * S * args.steps / dt
+        hbm_equiv = alg["A_ll"] * S / kern_s
+        flops = alg["W_ll"] * S / kern_s
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_cfg%d.json" % args.config)
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        if kernel_kind == 1:
+            # fused register-stack traversal: partial vectors never reach HBM, so the
+            # north-star HBM model (A_ll bytes/site) does not bound it; fp64 FMA does.
+            roofline = dict(bound="mfma", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
+                            frac=flops / FP64_PEAK, traffic=traffic,
+                            kernel="k_ll_fused4", kernel_ms=kern_s * 1e3,
+                            note="fp64 vector FMA (fp64 MFMA dense peak is the same 78.6 TFLOP/s); "
+                                 "algorithmic flops W_ll=%d/site" % alg["W_ll"],
+                            hbm_model_equiv=dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                                                 frac=hbm_equiv / HBM_PEAK,
+                                                 note="A_ll=%d B/site of the HBM-resident-partials design" % alg["A_ll"]))
+        else:
+            roofline = dict(bound="hbm", achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                            frac=hbm_equiv / HBM_PEAK, traffic=traffic,
+                            kernel="k_ll_generic", kernel_ms=kern_s * 1e3,
+                            note="A_ll=%d B/site" % alg["A_ll"])
+        out = {
+            "metric": "sites/sec (arbplf-ll)", "value": value, "unit": "sites/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: %s, %d sites per GPU, site-sharded" % (args.config, wl.name, S),
+                       "sites_per_gpu": S, "states": wl.k, "categories": wl.prepare()["C"], "taxa": wl.T,
+                       "parallelism": "site-shard x%d" % world},
+            "ll_sum": total,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_ll = cpu_baseline(wl, min(S, 2_000_000), args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/*
+ * plk.h -- C-ABI of the MI355X pruning-likelihood engine (libarbplf_amd.so).
+ *
+ * This is the device boundary of the drop-in: everything above it is host C
+ * (model parsing, tree, rate mixtures, reductions, JSON), everything below it
+ * is hand-written HIP for gfx950.  The entry points replace, one for one, the
+ * pieces of the reference (argriffing/phyly, paths relative to its root) that
+ * its three query drivers call between "model parsed" and "table written":
+ *
+ *   plk_set_tree        <- csr_graph_struct + navigation preorder
+ *                          (src/csr_graph.h:17-24, src/model.h:62-67)
+ *   plk_set_model       <- cross_site_ws_update: normalised Q, category
+ *                          rates/priors, P[c][e] = exp(Q r_c t_e)
+ *                          (src/cross_site_ws.c:151-168, :200-242)
+ *   plk_set_patterns_*  <- pmat_struct observation likelihoods
+ *                          (src/model.h:41-47, src/parsemodel.c:459-628)
+ *   plk_ll              <- ll _nd_accum_update: site loop x category loop x
+ *                          evaluate_site_lhood + log + site aggregation
+ *                          (src/arbplfll.c:110-177, src/evaluate_site_lhood.c:7-63)
+ *   plk_deriv           <- deriv _nd_accum_update + evaluate_site_derivatives
+ *                          (src/arbplfderiv.c:112-371)
+ *   plk_marginal        <- marginal _nd_accum_update + evaluate_site_forward +
+ *                          evaluate_site_marginal_unnormalized
+ *                          (src/arbplfmarginal.c:111-264)
+ *
+ * Conventions: every function returns 0 on success and a nonzero PLK_E_* code
+ * on failure (plk_last_error() gives the text).  The caller owns all buffers
+ * it passes; the engine owns its device memory.  Calls are synchronous.  One
+ * engine may be used from one thread at a time; distinct engines are
+ * independent (one per GPU / per process rank).  There is no CPU fallback: if
+ * no gfx950 device is usable, plk_create fails.
+ *
+ * Edge indices at this boundary are CSR edge indices (position in
+ * `indices`), as in the reference's cross_site_ws; the host layer maps user
+ * edge order <-> CSR order (src/csr_graph.c:29-46).
+ */
+#ifndef PLK_H
+#define PLK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plk_engine plk_engine;
+
+enum {
+    PLK_OK = 0,
+    PLK_E_DEVICE = 1,    /* no usable GPU / HIP runtime error */
+    PLK_E_ARG = 2,       /* invalid argument or call order */
+    PLK_E_NOMEM = 3,     /* host or device allocation failed */
+    PLK_E_UNSUPPORTED = 4
+};
+
+/* root prior modes, numbered as enum root_prior_mode in src/model.h:16-21 */
+enum {
+    PLK_ROOT_NONE = 1,        /* plain sum over root states */
+    PLK_ROOT_CUSTOM = 2,      /* root_w = user distribution */
+    PLK_ROOT_UNIFORM = 3,     /* 1/k */
+    PLK_ROOT_EQUILIBRIUM = 4  /* root_w = stationary distribution */
+};
+
+/* where a caller buffer lives */
+enum { PLK_HOST = 0, PLK_DEVICE = 1 };
+
+/* Create an engine on HIP device `device` (0-based).  Fails loudly
+ * (PLK_E_DEVICE) when the HIP runtime reports no device. */
+int plk_create(plk_engine **out, int device);
+void plk_destroy(plk_engine *h);
+const char *plk_last_error(const plk_engine *h);
+/* text for failures of plk_create itself (no engine yet) */
+const char *plk_create_error(void);
+
+/* Tree in CSR out-adjacency form; `preorder` is the BFS order from the root
+ * (preorder[0] = root), all host arrays.  N nodes, E = N-1 edges. */
+int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *indices,
+                 const int *preorder);
+
+/* Model: k states, C rate categories.
+ * Qn[k*k] row-major: rate matrix already divided by the rate divisor, with
+ * its diagonal set to minus the row sums (src/cross_site_ws.c:217-232).
+ * edge_rates_csr[E], cat_rates[C], cat_prior[C], root_w[k] (ignored for
+ * NONE/UNIFORM).  Runs the device exp(Q r t) kernel for all (c, e). */
+int plk_set_model(plk_engine *h, int k, int C, const double *Qn,
+                  const double *edge_rates_csr,
+                  const double *cat_rates, const double *cat_prior,
+                  int root_mode, const double *root_w);
+
+/* Recompute P for new edge rates only (branch-length optimisation loops). */
+int plk_update_edge_rates(plk_engine *h, const double *edge_rates_csr);
+
+/* Observations, compact form: codes[N][S] (site index fastest, one byte per
+ * node per site) + definitions defs[nchar][k] (host).  `where` says whether
+ * `codes` is a host or a device pointer; the engine copies it either way. */
+int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *codes, int where,
+                           int nchar, const double *defs);
+
+/* Observations, dense form: B[N][k][S] doubles (site index fastest). */
+int plk_set_patterns_dense(plk_engine *h, long S, const double *B, int where);
+
+/* Optional per-site weights for the aggregated outputs (NULL = all 1).
+ * A weight of exactly 0 still evaluates the site; selection is the caller's. */
+int plk_set_site_weights(plk_engine *h, const double *w, int where);
+
+/*
+ * Log likelihoods.  site_ll_out: NULL or S doubles (host/device per `where`).
+ * sum_out: NULL or 2 doubles {hi, lo}: sum_s w_s * ll_s as an unevaluated
+ * double-double (hi + lo), summed in a fixed order (deterministic).
+ */
+int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out);
+
+/*
+ * Edge-rate derivatives d ll_s / d edge_rate_coefficient_e (CSR edge order).
+ * edge_mask: NULL (all) or E ints, nonzero = requested.
+ * site_edge_out: NULL or [S][E] doubles, host; unrequested edges get 0.
+ * edge_sums_out: NULL or [E][2] double-double sums of w_s * d_{s,e}.
+ */
+int plk_deriv(plk_engine *h, const int *edge_mask,
+              double *site_edge_out, double *edge_sums_out);
+
+/*
+ * Marginal state distributions.  node_mask: NULL (all) or N ints.
+ * site_out: NULL or [S][N][k] doubles, host (unrequested nodes get 0).
+ * sums_out: NULL or [N][k][2] double-double sums over sites of w_s * m_{s,a,i}.
+ */
+int plk_marginal(plk_engine *h, const int *node_mask,
+                 double *site_out, double *sums_out);
+
+/* Introspection for tests and profiling. */
+int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
+int plk_get_info(plk_engine *h, int what, long *out);
+enum {
+    PLK_INFO_LL_KERNEL = 0,       /* 0 = none yet, 1 = fused register-stack (k=4), 2 = generic */
+    PLK_INFO_STACK_SLOTS = 1,     /* register-stack slots the tree needs */
+    PLK_INFO_PROGRAM_OPS = 2,     /* ops in the traversal program */
+    PLK_INFO_LAST_LL_KERNEL_NS = 3, /* HIP-event time of the last ll traversal kernel */
+    PLK_INFO_LAST_LL_TOTAL_NS = 4   /* HIP-event time of the last whole plk_ll device work */
+};
+
+/* force the generic (HBM-resident partials) traversal even where the fused
+ * kernel applies; used by tests and by bench.py --kernel generic */
+int plk_set_option(plk_engine *h, int option, long value);
+enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1 };
+
+#ifdef __cplusplus
+}
+#endif
+#endif

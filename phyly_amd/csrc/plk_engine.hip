@@ -1,0 +1,1165 @@
+/*
+ * plk_engine.hip -- MI355X (gfx950) pruning-likelihood engine behind include/plk.h.
+ *
+ * Kernels (all fp64; see DESIGN.md for layouts and rooflines):
+ *   k_expm_dd        P[c][e] = exp(Qn * r_c * t_e) in double-double arithmetic,
+ *                    one workgroup per (c, e); replaces arb_mat_exp in
+ *                    src/cross_site_ws.c:151-168 of the reference.
+ *   k_build_stream   gathers the rounded P matrices into traversal-program order
+ *   k_build_tip      tip tables P_e * defs[code] for leaf edges (k = 4 fused path)
+ *   k_ll_fused4      fused post-order traversal, one site per lane, partial vectors
+ *                    in a register stack, P matrices as scalar (SGPR) operands,
+ *                    tip tables + pattern codes staged in LDS; replaces the
+ *                    site x category x node loops of src/arbplfll.c:139-170 +
+ *                    src/evaluate_site_lhood.c:21-57 + src/util.c:242-301.
+ *   k_ll_generic<K>  the same traversal program for any k <= 64 with the
+ *                    stack slots resident in HBM ([slot][state][site], site fastest).
+ *   k_down_store<K>, k_up<K>   down pass with stored edge/node vectors and the
+ *                    BFS-order up pass for edge derivatives and marginals
+ *                    (src/evaluate_site_forward.c:32-105, src/arbplfderiv.c:112-371,
+ *                    src/arbplfmarginal.c:111-264).
+ *   k_wsum_*         deterministic double-double weighted reductions over sites
+ *                    (src/ndaccum.c:198-254 for aggregated site axes).
+ *
+ * There is no CPU path in this file: every entry point needs a HIP device.
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "plk.h"
+#include "plk_dd.h"
+
+#define PLK_MAX_K 64
+#define PLK_MAX_C 64
+#define PLK_FUSED_SLOTS 12
+#define PLK_TILE 256
+
+/* traversal program opcodes */
+enum {
+    OP_TIP_SET = 0,   /* cur  = P_e * B_b         (b a leaf child)          */
+    OP_TIP_MUL = 1,   /* cur *= P_e * B_b                                   */
+    OP_MATVEC = 2,    /* cur  = P_e * cur         (b an internal child)     */
+    OP_PUSH = 3,      /* slot[d] = cur                                      */
+    OP_POPMUL = 4,    /* cur *= slot[d]                                     */
+    OP_NODE_MUL = 5,  /* cur *= B_a               (internal node with data) */
+    OP_SCALE = 6,     /* cur *= 2^-e, exponent accumulated (exact)          */
+    OP_END = 7
+};
+/* op.x = opcode | (tip_slot << 8); op.y = node (TIP/NODE), slot (PUSH/POP) */
+
+struct plk_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::string err;
+
+    /* tree */
+    int N = 0, E = 0;
+    std::vector<int> indptr, indices, preorder, b_to_idx, idx_to_a;
+    int *d_indptr = nullptr, *d_indices = nullptr, *d_preorder = nullptr;
+
+    /* model */
+    int k = 0, C = 0, K = 0, root_mode = 0;
+    std::vector<double> Qn, edge_rates, cat_rates, cat_prior, root_w;
+    double *d_Qn = nullptr, *d_edge_rates = nullptr, *d_cat_rates = nullptr, *d_cat_prior = nullptr;
+    double *d_root_w = nullptr;          /* K, zero padded; the weights of the root dot */
+    dd *d_Pdd = nullptr;                 /* [C][E][k*k] unrounded */
+    double *d_P = nullptr, *d_dP = nullptr; /* [C][E][k][k] rounded; dP = r_c Qn P */
+    dd *d_scratch = nullptr;
+    bool model_dirty = true;
+
+    /* patterns */
+    long S = 0, Spad = 0;
+    int pat_mode = 0;                    /* 0 none, 1 codes, 2 dense */
+    uint8_t *d_codes = nullptr;          /* [N][Spad] */
+    int nchar = 0;
+    std::vector<double> defs;            /* [nchar][k] host */
+    double *d_defs = nullptr;            /* [nchar][K] zero padded */
+    double *d_B = nullptr;               /* [N][k][S] */
+    std::vector<char> node_has_data;     /* internal nodes whose observations are not all-ones */
+    double *d_w = nullptr;
+
+    /* traversal program */
+    bool prog_dirty = true, stream_dirty = true;
+    std::vector<int2> ops;
+    std::vector<int> op_edge;            /* CSR edge per op or -1 */
+    std::vector<int> tip_edge;           /* CSR edge per tip slot */
+    std::vector<int> obs_nodes;          /* nodes whose codes the fused kernel stages */
+    int slots_needed = 0;
+    int2 *d_ops = nullptr;
+    int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr;
+    double *d_PS = nullptr;              /* [C][nops][K*K] transposed: PS[j*K+i] = P[i][j] */
+    double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
+    size_t ps_cap = 0, tip_cap = 0;
+
+    /* workspaces */
+    double *d_slots = nullptr; size_t slots_cap = 0;
+    double *d_site_ll = nullptr; size_t site_ll_cap = 0;
+    dd *d_partial = nullptr; size_t partial_cap = 0;
+    double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
+
+    /* options / info */
+    long opt_force_generic = 0, opt_site_chunk = 0;
+    long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0;
+};
+
+static std::string g_create_error;
+
+#define HIPCHK(h, call)                                                            \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);         \
+            return PLK_E_DEVICE;                                                   \
+        }                                                                          \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(plk_engine *h, T **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        *p = nullptr;
+        return PLK_E_NOMEM;
+    }
+    return PLK_OK;
+}
+
+template <typename T>
+static int dev_upload(plk_engine *h, T **p, const T *src, size_t n)
+{
+    int rc = dev_alloc(h, p, n);
+    if (rc) return rc;
+    if (n) HIPCHK(h, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PLK_OK;
+}
+
+template <typename T>
+static int dev_reserve(plk_engine *h, T **p, size_t *cap, size_t n)
+{
+    if (*p && *cap >= n) return PLK_OK;
+    int rc = dev_alloc(h, p, n);
+    *cap = rc ? 0 : n;
+    return rc;
+}
+
+/* ====================================================================== */
+/* K1: P = exp(Qn * r_c * t_e) in double-double                            */
+/* ====================================================================== */
+
+__device__ static inline dd dd_div_d(dd x, double y)
+{
+    double q1 = x.hi / y;
+    dd p = dd_two_prod(q1, y);
+    dd r = dd_add(x, dd_make(-p.hi, -p.lo));
+    double q2 = r.hi / y;
+    return dd_quick_two_sum(q1, q2);
+}
+
+__device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
+{
+    int kk = k * k;
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+        int i = idx / k, j = idx - i * k;
+        dd acc = dd_make(0.0, 0.0);
+        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(A[i * k + l], B[l * k + j]));
+        Cm[idx] = acc;
+    }
+}
+
+#define EXPM_TERMS 28
+
+__global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn,
+                          const double *__restrict__ edge_rates,
+                          const double *__restrict__ cat_rates,
+                          dd *__restrict__ Pdd, double *__restrict__ P, double *__restrict__ dP,
+                          dd *gscratch, int use_lds)
+{
+    extern __shared__ double smem_raw[];
+    __shared__ double s_row[PLK_MAX_K];
+    __shared__ int s_sq;
+    const int ce = blockIdx.x;
+    const int c = ce / E, e = ce - c * E;
+    const int kk = k * k;
+    dd *base = use_lds ? reinterpret_cast<dd *>(smem_raw) : gscratch + (size_t)ce * 4 * kk;
+    dd *X = base, *T = base + kk, *O = base + 2 * kk, *W = base + 3 * kk;
+
+    const dd s = dd_two_prod(cat_rates[c], edge_rates[e]);
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_mul_d(s, Qn[idx]);
+    __syncthreads();
+    if ((int)threadIdx.x < k) {
+        double r = 0;
+        for (int j = 0; j < k; j++) r += fabs(X[threadIdx.x * k + j].hi);
+        s_row[threadIdx.x] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double norm = 0;
+        for (int i = 0; i < k; i++) norm = fmax(norm, s_row[i]);
+        int sq = 0;
+        while (norm > 0.5) { norm *= 0.5; sq++; }
+        s_sq = sq;
+    }
+    __syncthreads();
+    const int sq = s_sq;
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+        dd x = dd_ldexp(X[idx], -sq);
+        X[idx] = x;
+        T[idx] = x;
+        int i = idx / k, j = idx - i * k;
+        O[idx] = (i == j) ? dd_add_d(x, 1.0) : x;
+    }
+    __syncthreads();
+    for (int n = 2; n <= EXPM_TERMS; n++) {
+        dd_matmul_block(k, T, X, W);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+            dd t = dd_div_d(W[idx], (double)n);
+            T[idx] = t;
+            O[idx] = dd_add(O[idx], t);
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < sq; q++) {
+        dd_matmul_block(k, O, O, W);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = W[idx];
+        __syncthreads();
+    }
+    /* outputs: unrounded P, rounded P, rounded dP = r_c * Qn * P */
+    const double rc = cat_rates[c];
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+        dd v = O[idx];
+        if (v.hi < 0) v = dd_make(0.0, 0.0);
+        Pdd[(size_t)ce * kk + idx] = v;
+        P[(size_t)ce * kk + idx] = v.hi;
+        int i = idx / k, j = idx - i * k;
+        dd acc = dd_make(0.0, 0.0);
+        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul_d(O[l * k + j], Qn[i * k + l]));
+        acc = dd_mul_d(acc, rc);
+        dP[(size_t)ce * kk + idx] = acc.hi;
+    }
+}
+
+/* PS[c][pc][j*K + i] = P[c][edge(pc)][i][j], zero padded to K (transposed so that
+ * the column needed for one input state is contiguous for scalar loads) */
+__global__ void k_build_stream(int k, int K, int E, int nops, const int *__restrict__ op_edge,
+                               const double *__restrict__ P, double *__restrict__ PS)
+{
+    const int pc = blockIdx.x, c = blockIdx.y;
+    const int e = op_edge[pc];
+    double *dst = PS + ((size_t)c * nops + pc) * K * K;
+    for (int idx = threadIdx.x; idx < K * K; idx += blockDim.x) {
+        int j = idx / K, i = idx - j * K;
+        double v = 0.0;
+        if (e >= 0 && i < k && j < k) v = P[((size_t)c * E + e) * k * k + i * k + j];
+        dst[idx] = v;
+    }
+}
+
+/* tip[c][t][code][i] = sum_j P[c][edge(t)][i][j] * defs[code][j] in dd (k = 4).
+ * An exactly constant definition row (e.g. all-ones "missing") maps to itself,
+ * which is what the reference's exact shortcut produces (src/util.c:276-283). */
+__global__ void k_build_tip(int E, int ntips, int nchar, const int *__restrict__ tip_edge,
+                            const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][4] */,
+                            double *__restrict__ tip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int e = tip_edge[t];
+    const dd *Pm = Pdd + ((size_t)c * E + e) * 16;
+    for (int idx = threadIdx.x; idx < nchar * 4; idx += blockDim.x) {
+        int code = idx >> 2, i = idx & 3;
+        const double *d = defs + code * 4;
+        double out;
+        if (d[0] == d[1] && d[0] == d[2] && d[0] == d[3]) {
+            out = d[0];
+        } else {
+            dd acc = dd_make(0.0, 0.0);
+            for (int j = 0; j < 4; j++) acc = dd_add(acc, dd_mul_d(Pm[i * 4 + j], d[j]));
+            out = acc.hi;
+        }
+        tip[(((size_t)c * ntips + t) * nchar + code) * 4 + i] = out;
+    }
+}
+
+/* flags[n] != 0 iff some site's code at node n is not an all-ones definition */
+__global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes,
+                             const int *__restrict__ code_trivial, int *__restrict__ flags)
+{
+    const int n = blockIdx.y;
+    long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (s < S) bad = !code_trivial[codes[(size_t)n * Spad + s]];
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[n], 1);
+}
+
+/* ====================================================================== */
+/* deterministic double-double reductions                                  */
+/* ====================================================================== */
+
+__device__ static inline dd dd_wave_sum(dd v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        dd o;
+        o.hi = __shfl_down(v.hi, off, 64);
+        o.lo = __shfl_down(v.lo, off, 64);
+        v = dd_add(v, o);
+    }
+    return v;
+}
+
+/* block-wide dd sum, result valid in thread 0; blockDim.x multiple of 64, <= 1024 */
+__device__ static inline dd dd_block_sum(dd v)
+{
+    __shared__ double sh_hi[16], sh_lo[16];
+    v = dd_wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sh_hi[wave] = v.hi; sh_lo[wave] = v.lo; }
+    __syncthreads();
+    dd r = dd_make(0.0, 0.0);
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; i++) r = dd_add(r, dd_make(sh_hi[i], sh_lo[i]));
+    }
+    return r;
+}
+
+/* out[row] = sum over blocks of partial[row][block]; one block per row */
+__global__ void k_dd_final(int nblocks, const dd *__restrict__ partial, dd *__restrict__ out)
+{
+    const int row = blockIdx.x;
+    dd acc = dd_make(0.0, 0.0);
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc = dd_add(acc, partial[(size_t)row * nblocks + b]);
+    dd r = dd_block_sum(acc);
+    if (threadIdx.x == 0) out[row] = r;
+}
+
+/* partial[row][block] = sum_{s in block's range} w[s] * X[row][s] */
+__global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ X,
+                            const double *__restrict__ w, int nblocks, dd *__restrict__ partial)
+{
+    const int row = blockIdx.y;
+    const long per = (S + nblocks - 1) / nblocks;
+    const long lo = (long)blockIdx.x * per;
+    const long hi = lo + per < S ? lo + per : S;
+    dd acc = dd_make(0.0, 0.0);
+    for (long s = lo + threadIdx.x; s < hi; s += blockDim.x) {
+        double x = X[(size_t)row * row_stride + s];
+        dd t = w ? dd_two_prod(w[s], x) : dd_make(x, 0.0);
+        acc = dd_add(acc, t);
+    }
+    dd r = dd_block_sum(acc);
+    if (threadIdx.x == 0) partial[(size_t)row * nblocks + blockIdx.x] = r;
+}
+
+/* ====================================================================== */
+/* K2+K3 fused: k = 4, register stack                                      */
+/* ====================================================================== */
+
+struct FusedArgs {
+    long S, Spad;
+    int C, nops, ntips, nchar, nobs;
+    int root_mode;
+    const int2 *ops;
+    const double *PS;        /* [C][nops][16] transposed */
+    const double *tip;       /* [C][ntips][nchar][4] */
+    const uint8_t *codes;    /* [N][Spad] */
+    const int *obs_nodes;    /* [nobs] node per staged row */
+    const double *defs;      /* [nchar][4] */
+    const double *cat_prior; /* [C] */
+    const double *root_w;    /* [4] */
+    const double *w;         /* site weights or null */
+    double *site_ll;         /* [S] or null */
+    dd *partial;             /* [gridDim.x] or null */
+};
+
+__device__ static inline int frexp_exp(double m)
+{
+    /* exponent e with m = f * 2^e, 0.5 <= f < 1; 0 for m == 0 */
+    return m > 0.0 ? __builtin_amdgcn_frexp_exp(m) : 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
+{
+    extern __shared__ double lds_dyn[];
+    /* LDS: tip table of the current category, then the staged codes of this tile */
+    double *tip_lds = lds_dyn;
+    const int tip_doubles = a.ntips * a.nchar * 4;
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_dyn + tip_doubles);
+
+    const long tile0 = (long)blockIdx.x * PLK_TILE;
+    const int tid = threadIdx.x;
+    const long s = tile0 + tid;
+    const bool valid = s < a.S;
+
+    /* stage codes[obs][256] for this tile: rows are padded to Spad (multiple of 256) */
+    {
+        const int ndw = a.nobs * (PLK_TILE / 4);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
+        for (int idx = tid; idx < ndw; idx += PLK_TILE) {
+            int row = idx >> 6, col = idx & 63;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad + tile0);
+            dst[idx] = src[col];
+        }
+    }
+
+    double sum = 0.0;
+    int Eexp = 0;
+    bool have = false;
+
+    for (int c = 0; c < a.C; c++) {
+        __syncthreads();
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(a.tip + (size_t)c * tip_doubles);
+            double2 *dst = reinterpret_cast<double2 *>(tip_lds);
+            for (int idx = tid; idx < tip_doubles / 2; idx += PLK_TILE) dst[idx] = src[idx];
+        }
+        __syncthreads();
+
+        double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;
+        double st[D][4];
+#pragma unroll
+        for (int d = 0; d < D; d++) { st[d][0] = st[d][1] = st[d][2] = st[d][3] = 0.0; }
+        int esc = 0;
+        const double *PSc = a.PS + (size_t)c * a.nops * 16;
+
+        for (int pc = 0; pc < a.nops; pc++) {
+            const int2 op = a.ops[pc];
+            const int code = op.x & 0xff;
+            if (code == OP_MATVEC) {
+                const double *M = PSc + (size_t)pc * 16;
+                double n0 = M[0] * c0, n1 = M[1] * c0, n2 = M[2] * c0, n3 = M[3] * c0;
+                n0 = fma(M[4], c1, n0); n1 = fma(M[5], c1, n1); n2 = fma(M[6], c1, n2); n3 = fma(M[7], c1, n3);
+                n0 = fma(M[8], c2, n0); n1 = fma(M[9], c2, n1); n2 = fma(M[10], c2, n2); n3 = fma(M[11], c2, n3);
+                n0 = fma(M[12], c3, n0); n1 = fma(M[13], c3, n1); n2 = fma(M[14], c3, n2); n3 = fma(M[15], c3, n3);
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+                const int t = op.x >> 8;
+                const int ch = code_lds[op.y * PLK_TILE + tid];
+                const double2 *tp = reinterpret_cast<const double2 *>(tip_lds + ((size_t)t * a.nchar + ch) * 4);
+                const double2 v01 = tp[0], v23 = tp[1];
+                if (code == OP_TIP_SET) { c0 = v01.x; c1 = v01.y; c2 = v23.x; c3 = v23.y; }
+                else { c0 *= v01.x; c1 *= v01.y; c2 *= v23.x; c3 *= v23.y; }
+            } else if (code == OP_PUSH) {
+                const int d = op.y;
+#pragma unroll
+                for (int i = 0; i < D; i++)
+                    if (d == i) { st[i][0] = c0; st[i][1] = c1; st[i][2] = c2; st[i][3] = c3; }
+            } else if (code == OP_POPMUL) {
+                const int d = op.y;
+#pragma unroll
+                for (int i = 0; i < D; i++)
+                    if (d == i) { c0 *= st[i][0]; c1 *= st[i][1]; c2 *= st[i][2]; c3 *= st[i][3]; }
+            } else if (code == OP_NODE_MUL) {
+                const int ch = code_lds[op.y * PLK_TILE + tid];
+                const double *dv = a.defs + ch * 4;
+                c0 *= dv[0]; c1 *= dv[1]; c2 *= dv[2]; c3 *= dv[3];
+            } else if (code == OP_SCALE) {
+                const double m = fmax(fmax(c0, c1), fmax(c2, c3));
+                const int e = frexp_exp(m);
+                c0 = ldexp(c0, -e); c1 = ldexp(c1, -e); c2 = ldexp(c2, -e); c3 = ldexp(c3, -e);
+                esc += e;
+            }
+        }
+        /* root expectation (src/model.c:283-350) and category mixing (src/arbplfll.c:165) */
+        double lh;
+        if (a.root_mode == PLK_ROOT_NONE) lh = ((c0 + c1) + c2) + c3;
+        else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((c0 + c1) + c2) + c3) * 0.25;
+        else lh = fma(a.root_w[3], c3, fma(a.root_w[2], c2, fma(a.root_w[1], c1, a.root_w[0] * c0)));
+        const double term = a.cat_prior[c] * lh;
+        if (term != 0.0) {
+            if (!have) { sum = term; Eexp = esc; have = true; }
+            else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
+            else sum += ldexp(term, esc - Eexp);
+        }
+    }
+    const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
+    if (valid && a.site_ll) a.site_ll[s] = ll;
+    if (a.partial) {
+        dd v = dd_make(0.0, 0.0);
+        if (valid) v = a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0);
+        dd r = dd_block_sum(v);
+        if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+/* ====================================================================== */
+/* K2+K3 generic: any k <= K, stack slots in HBM                           */
+/* ====================================================================== */
+
+struct GenArgs {
+    long S, Spad;
+    int k, C, nops, nchar, pat_mode, root_mode;
+    const int2 *ops;
+    const double *PS;        /* [C][nops][K*K] transposed, zero padded */
+    const uint8_t *codes;    /* [N][Spad] */
+    const double *defs;      /* [nchar][K] zero padded */
+    const double *B;         /* [N][k][S] */
+    const double *cat_prior, *root_w, *w;
+    double *slots;           /* [nslots][k][S] */
+    double *site_ll;
+    dd *partial;
+};
+
+#define GEN_BLOCK 64
+
+template <int K>
+__device__ static inline void gen_load_obs(const GenArgs &a, int node, long sc, int tid, double (*xs)[GEN_BLOCK])
+{
+    if (a.pat_mode == 1) {
+        const int ch = a.codes[(size_t)node * a.Spad + sc];
+        const double *dv = a.defs + (size_t)ch * K;
+        for (int j = 0; j < a.k; j++) xs[j][tid] = dv[j];
+    } else {
+        const double *bp = a.B + (size_t)node * a.k * a.S + sc;
+        for (int j = 0; j < a.k; j++) xs[j][tid] = bp[(size_t)j * a.S];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(GEN_BLOCK) void k_ll_generic(GenArgs a)
+{
+    __shared__ double xs[K][GEN_BLOCK];
+    const int tid = threadIdx.x;
+    const long s = (long)blockIdx.x * GEN_BLOCK + tid;
+    const bool valid = s < a.S;
+    const long sc = valid ? s : a.S - 1;
+
+    double sum = 0.0;
+    int Eexp = 0;
+    bool have = false;
+
+    for (int c = 0; c < a.C; c++) {
+        double cur[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) cur[i] = 1.0;
+        int esc = 0;
+        const double *PSc = a.PS + (size_t)c * a.nops * K * K;
+        for (int pc = 0; pc < a.nops; pc++) {
+            const int2 op = a.ops[pc];
+            const int code = op.x & 0xff;
+            if (code == OP_MATVEC || code == OP_TIP_SET || code == OP_TIP_MUL) {
+                if (code == OP_MATVEC) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) xs[j][tid] = cur[j];
+                } else {
+                    gen_load_obs<K>(a, op.y, sc, tid, xs);
+                }
+                const double *M = PSc + (size_t)pc * K * K;
+                double acc[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) acc[i] = 0.0;
+                for (int j = 0; j < a.k; j++) {
+                    const double x = xs[j][tid];
+                    const double *col = M + j * K;
+#pragma unroll
+                    for (int i = 0; i < K; i++) acc[i] = fma(col[i], x, acc[i]);
+                }
+                if (code == OP_TIP_MUL) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) cur[i] *= acc[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) cur[i] = acc[i];
+                }
+            } else if (code == OP_PUSH) {
+                double *sp = a.slots + (size_t)op.y * a.k * a.S + sc;
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if (i < a.k && valid) sp[(size_t)i * a.S] = cur[i];
+            } else if (code == OP_POPMUL) {
+                const double *sp = a.slots + (size_t)op.y * a.k * a.S + sc;
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if (i < a.k) cur[i] *= valid ? sp[(size_t)i * a.S] : 1.0;
+            } else if (code == OP_NODE_MUL) {
+                gen_load_obs<K>(a, op.y, sc, tid, xs);
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if (i < a.k) cur[i] *= xs[i][tid];
+            } else if (code == OP_SCALE) {
+                double m = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) m = fmax(m, cur[i]);
+                const int e = frexp_exp(m);
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] = ldexp(cur[i], -e);
+                esc += e;
+            }
+        }
+        double lh = 0.0;
+        if (a.root_mode == PLK_ROOT_NONE || a.root_mode == PLK_ROOT_UNIFORM) {
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (i < a.k) lh += cur[i];
+            if (a.root_mode == PLK_ROOT_UNIFORM) lh /= (double)a.k;
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; i++) lh = fma(a.root_w[i], cur[i], lh);
+        }
+        const double term = a.cat_prior[c] * lh;
+        if (term != 0.0) {
+            if (!have) { sum = term; Eexp = esc; have = true; }
+            else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
+            else sum += ldexp(term, esc - Eexp);
+        }
+    }
+    const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
+    if (valid && a.site_ll) a.site_ll[s] = ll;
+    if (a.partial) {
+        dd v = dd_make(0.0, 0.0);
+        if (valid) v = a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0);
+        dd r = dd_block_sum(v);
+        if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+/* ====================================================================== */
+/* host side                                                               */
+/* ====================================================================== */
+
+static int pad_K(int k)
+{
+    const int ks[] = {2, 4, 8, 16, 20, 32, 61, 64};
+    for (int v : ks) if (k <= v) return v;
+    return -1;
+}
+
+extern "C" const char *plk_create_error(void) { return g_create_error.c_str(); }
+
+extern "C" int plk_create(plk_engine **out, int device)
+{
+    if (!out) return PLK_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("plk_create: no HIP device available (") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                         "); this engine has no CPU fallback";
+        return PLK_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "plk_create: device index out of range";
+        return PLK_E_ARG;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return PLK_E_DEVICE;
+    }
+    plk_engine *h = new plk_engine();
+    h->device = device;
+    if (hipStreamCreate(&h->stream) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreate(&h->ev2) != hipSuccess || hipEventCreate(&h->ev3) != hipSuccess) {
+        g_create_error = "plk_create: stream/event creation failed";
+        delete h;
+        return PLK_E_DEVICE;
+    }
+    *out = h;
+    return PLK_OK;
+}
+
+extern "C" void plk_destroy(plk_engine *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
+                    h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
+                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
+                    h->d_PS, h->d_tip, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char *plk_last_error(const plk_engine *h) { return h ? h->err.c_str() : "null engine"; }
+
+extern "C" int plk_set_option(plk_engine *h, int option, long value)
+{
+    if (!h) return PLK_E_ARG;
+    if (option == PLK_OPT_FORCE_GENERIC) { h->opt_force_generic = value; h->prog_dirty = true; return PLK_OK; }
+    if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
+    h->err = "plk_set_option: unknown option";
+    return PLK_E_ARG;
+}
+
+extern "C" int plk_get_info(plk_engine *h, int what, long *out)
+{
+    if (!h || !out) return PLK_E_ARG;
+    switch (what) {
+    case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
+    case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
+    case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
+    case PLK_INFO_LAST_LL_KERNEL_NS: *out = h->info_ll_kernel_ns; return PLK_OK;
+    case PLK_INFO_LAST_LL_TOTAL_NS: *out = h->info_ll_total_ns; return PLK_OK;
+    }
+    h->err = "plk_get_info: unknown item";
+    return PLK_E_ARG;
+}
+
+extern "C" int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *indices, const int *preorder)
+{
+    if (!h) return PLK_E_ARG;
+    if (N < 2 || !indptr || !indices || !preorder) { h->err = "plk_set_tree: bad arguments"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int E = N - 1;
+    if (indptr[0] != 0 || indptr[N] != E) { h->err = "plk_set_tree: indptr does not describe N-1 edges"; return PLK_E_ARG; }
+    std::vector<int> b2i(N, -1), i2a(E, -1);
+    for (int a = 0; a < N; a++) {
+        if (indptr[a + 1] < indptr[a]) { h->err = "plk_set_tree: indptr not monotone"; return PLK_E_ARG; }
+        for (int idx = indptr[a]; idx < indptr[a + 1]; idx++) {
+            int b = indices[idx];
+            if (b < 0 || b >= N || b == a || b2i[b] != -1) { h->err = "plk_set_tree: not a tree"; return PLK_E_ARG; }
+            b2i[b] = idx;
+            i2a[idx] = a;
+        }
+    }
+    std::vector<char> seen(N, 0);
+    for (int u = 0; u < N; u++) {
+        int a = preorder[u];
+        if (a < 0 || a >= N || seen[a]) { h->err = "plk_set_tree: preorder is not a permutation"; return PLK_E_ARG; }
+        if (u == 0 ? b2i[a] != -1 : (b2i[a] == -1 || !seen[i2a[b2i[a]]])) {
+            h->err = "plk_set_tree: preorder does not start at the root / parents first";
+            return PLK_E_ARG;
+        }
+        seen[a] = 1;
+    }
+    h->N = N; h->E = E;
+    h->indptr.assign(indptr, indptr + N + 1);
+    h->indices.assign(indices, indices + E);
+    h->preorder.assign(preorder, preorder + N);
+    h->b_to_idx = b2i; h->idx_to_a = i2a;
+    int rc;
+    if ((rc = dev_upload(h, &h->d_indptr, indptr, (size_t)N + 1))) return rc;
+    if ((rc = dev_upload(h, &h->d_indices, indices, (size_t)E))) return rc;
+    if ((rc = dev_upload(h, &h->d_preorder, preorder, (size_t)N))) return rc;
+    h->prog_dirty = true;
+    h->model_dirty = true;
+    h->pat_mode = 0;
+    h->k = 0;
+    return PLK_OK;
+}
+
+static int run_expm(plk_engine *h)
+{
+    const int k = h->k, C = h->C, E = h->E;
+    const size_t kk = (size_t)k * k, n = (size_t)C * E * kk;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_Pdd, n))) return rc;
+    if ((rc = dev_alloc(h, &h->d_P, n))) return rc;
+    if ((rc = dev_alloc(h, &h->d_dP, n))) return rc;
+    const size_t lds_bytes = 4 * kk * sizeof(dd);
+    const int use_lds = lds_bytes <= 64 * 1024;
+    if (!use_lds) { if ((rc = dev_alloc(h, &h->d_scratch, (size_t)C * E * 4 * kk))) return rc; }
+    const int threads = kk >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_expm_dd, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+                       k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
+                       h->d_scratch, use_lds);
+    HIPCHK(h, hipGetLastError());
+    h->model_dirty = false;
+    h->stream_dirty = true;
+    return PLK_OK;
+}
+
+extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, const double *edge_rates_csr,
+                             const double *cat_rates, const double *cat_prior, int root_mode,
+                             const double *root_w)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->N == 0) { h->err = "plk_set_model: set the tree first"; return PLK_E_ARG; }
+    if (k < 1 || C < 1 || !Qn || !edge_rates_csr || !cat_rates || !cat_prior) { h->err = "plk_set_model: bad arguments"; return PLK_E_ARG; }
+    if (k > PLK_MAX_K) { h->err = "plk_set_model: more than 64 states is not supported yet"; return PLK_E_UNSUPPORTED; }
+    if (C > PLK_MAX_C) { h->err = "plk_set_model: more than 64 rate categories is not supported"; return PLK_E_UNSUPPORTED; }
+    if (root_mode < PLK_ROOT_NONE || root_mode > PLK_ROOT_EQUILIBRIUM) { h->err = "plk_set_model: bad root mode"; return PLK_E_ARG; }
+    if ((root_mode == PLK_ROOT_CUSTOM || root_mode == PLK_ROOT_EQUILIBRIUM) && !root_w) { h->err = "plk_set_model: root_w required"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->k != k) { h->pat_mode = 0; }
+    h->k = k; h->C = C; h->K = pad_K(k); h->root_mode = root_mode;
+    h->Qn.assign(Qn, Qn + (size_t)k * k);
+    h->edge_rates.assign(edge_rates_csr, edge_rates_csr + h->E);
+    h->cat_rates.assign(cat_rates, cat_rates + C);
+    h->cat_prior.assign(cat_prior, cat_prior + C);
+    std::vector<double> rw(h->K, 0.0);
+    for (int i = 0; i < k; i++) {
+        if (root_mode == PLK_ROOT_NONE) rw[i] = 1.0;
+        else if (root_mode == PLK_ROOT_UNIFORM) rw[i] = 1.0 / (double)k;
+        else rw[i] = root_w[i];
+    }
+    h->root_w = rw;
+    int rc;
+    if ((rc = dev_upload(h, &h->d_Qn, h->Qn.data(), h->Qn.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_edge_rates, h->edge_rates.data(), h->edge_rates.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_cat_rates, h->cat_rates.data(), h->cat_rates.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_cat_prior, h->cat_prior.data(), h->cat_prior.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_root_w, rw.data(), rw.size()))) return rc;
+    h->prog_dirty = true;
+    if ((rc = run_expm(h))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PLK_OK;
+}
+
+extern "C" int plk_update_edge_rates(plk_engine *h, const double *edge_rates_csr)
+{
+    if (!h || !edge_rates_csr) return PLK_E_ARG;
+    if (h->k == 0) { h->err = "plk_update_edge_rates: set the model first"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    h->edge_rates.assign(edge_rates_csr, edge_rates_csr + h->E);
+    HIPCHK(h, hipMemcpyAsync(h->d_edge_rates, h->edge_rates.data(), h->E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->model_dirty = true;
+    return PLK_OK;
+}
+
+extern "C" int plk_get_transition_matrices(plk_engine *h, double *P_out)
+{
+    if (!h || !P_out) return PLK_E_ARG;
+    if (h->k == 0) { h->err = "plk_get_transition_matrices: set the model first"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->model_dirty) { int rc = run_expm(h); if (rc) return rc; }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(P_out, h->d_P, (size_t)h->C * h->E * h->k * h->k * sizeof(double), hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+static int copy_in(plk_engine *h, void *dst, const void *src, size_t bytes, int where)
+{
+    HIPCHK(h, hipMemcpy(dst, src, bytes, where == PLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return PLK_OK;
+}
+
+extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *codes, int where, int nchar,
+                                      const double *defs)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->k == 0) { h->err = "plk_set_patterns_codes: set the model first"; return PLK_E_ARG; }
+    if (S < 1 || !codes || nchar < 1 || nchar > 256 || !defs) { h->err = "plk_set_patterns_codes: bad arguments"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int k = h->k, K = h->K, N = h->N;
+    const long Spad = (S + PLK_TILE - 1) / PLK_TILE * PLK_TILE;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_codes, (size_t)N * Spad))) return rc;
+    HIPCHK(h, hipMemset(h->d_codes, 0, (size_t)N * Spad));
+    HIPCHK(h, hipMemcpy2D(h->d_codes, Spad, codes, S, S, N,
+                          where == PLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    h->defs.assign(defs, defs + (size_t)nchar * k);
+    std::vector<double> dpad((size_t)nchar * K, 0.0);
+    std::vector<int> trivial(nchar, 1);
+    for (int ch = 0; ch < nchar; ch++)
+        for (int j = 0; j < k; j++) {
+            dpad[(size_t)ch * K + j] = defs[(size_t)ch * k + j];
+            if (defs[(size_t)ch * k + j] != 1.0) trivial[ch] = 0;
+        }
+    if ((rc = dev_upload(h, &h->d_defs, dpad.data(), dpad.size()))) return rc;
+    h->S = S; h->Spad = Spad; h->nchar = nchar; h->pat_mode = 1;
+    if (h->d_B) { (void)hipFree(h->d_B); h->d_B = nullptr; }
+    if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; }
+    /* which nodes carry observations that are not all-ones */
+    int *d_triv = nullptr, *d_flags = nullptr;
+    if ((rc = dev_upload(h, &d_triv, trivial.data(), trivial.size()))) return rc;
+    if ((rc = dev_alloc(h, &d_flags, (size_t)N))) { (void)hipFree(d_triv); return rc; }
+    HIPCHK(h, hipMemset(d_flags, 0, N * sizeof(int)));
+    hipLaunchKernelGGL(k_node_flags, dim3((unsigned)((S + 255) / 256), N), dim3(256), 0, h->stream,
+                       S, Spad, h->d_codes, d_triv, d_flags);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<int> flags(N);
+    HIPCHK(h, hipMemcpy(flags.data(), d_flags, N * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_triv); (void)hipFree(d_flags);
+    h->node_has_data.assign(N, 0);
+    for (int a = 0; a < N; a++) h->node_has_data[a] = flags[a] ? 1 : 0;
+    h->prog_dirty = true;
+    return PLK_OK;
+}
+
+extern "C" int plk_set_patterns_dense(plk_engine *h, long S, const double *B, int where)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->k == 0) { h->err = "plk_set_patterns_dense: set the model first"; return PLK_E_ARG; }
+    if (S < 1 || !B) { h->err = "plk_set_patterns_dense: bad arguments"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->N * h->k * S;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_B, n))) return rc;
+    if ((rc = copy_in(h, h->d_B, B, n * sizeof(double), where))) return rc;
+    if (h->d_codes) { (void)hipFree(h->d_codes); h->d_codes = nullptr; }
+    if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; }
+    h->S = S; h->Spad = S; h->pat_mode = 2; h->nchar = 0;
+    h->node_has_data.assign(h->N, 1);
+    h->prog_dirty = true;
+    return PLK_OK;
+}
+
+extern "C" int plk_set_site_weights(plk_engine *h, const double *w, int where)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->pat_mode == 0) { h->err = "plk_set_site_weights: set the patterns first"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!w) { if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; } return PLK_OK; }
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_w, (size_t)h->S))) return rc;
+    return copy_in(h, h->d_w, w, (size_t)h->S * sizeof(double), where);
+}
+
+/* ---------------------------------------------------------------------- */
+/* traversal program                                                       */
+/* ---------------------------------------------------------------------- */
+
+static int build_program(plk_engine *h)
+{
+    const int N = h->N;
+    const std::vector<int> &ip = h->indptr, &ix = h->indices;
+    std::vector<int> need(N, 0), since(N, 0);
+    std::vector<char> scale_here(N, 0);
+    std::vector<std::vector<int>> ichild(N); /* internal children (CSR edge idx), sorted by need desc */
+    for (int u = N - 1; u >= 0; u--) {
+        const int a = h->preorder[u];
+        if (ip[a + 1] == ip[a]) continue;
+        std::vector<int> &ic = ichild[a];
+        int acc = 0;
+        for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
+            const int b = ix[idx];
+            acc += since[b] + 1;
+            if (ip[b + 1] > ip[b]) ic.push_back(idx);
+        }
+        std::stable_sort(ic.begin(), ic.end(), [&](int x, int y) { return need[ix[x]] > need[ix[y]]; });
+        int nd = 0;
+        for (size_t i = 0; i < ic.size(); i++) nd = std::max(nd, need[ix[ic[i]]] + (i > 0 ? 1 : 0));
+        need[a] = nd;
+        if (acc >= 16) { scale_here[a] = 1; acc = 0; }
+        since[a] = acc;
+    }
+    const int root = h->preorder[0];
+    h->slots_needed = need[root];
+
+    h->ops.clear(); h->op_edge.clear(); h->tip_edge.clear(); h->obs_nodes.clear();
+    std::vector<int> obs_row(N, -1);
+    auto obs = [&](int node) {
+        if (obs_row[node] < 0) { obs_row[node] = (int)h->obs_nodes.size(); h->obs_nodes.push_back(node); }
+        return obs_row[node];
+    };
+    auto emit = [&](int code, int tslot, int arg, int edge) {
+        int2 o; o.x = code | (tslot << 8); o.y = arg;
+        h->ops.push_back(o); h->op_edge.push_back(edge);
+    };
+    /* iterative post-order emission; frame = (node, depth, stage) */
+    struct Frame { int a, depth, stage; bool started; };
+    std::vector<Frame> stk;
+    stk.push_back({root, 0, 0, false});
+    while (!stk.empty()) {
+        Frame &f = stk.back();
+        const int a = f.a;
+        const std::vector<int> &ic = ichild[a];
+        if (f.stage == 0) {
+            f.stage = 1;
+            if (!ic.empty()) { stk.push_back({ix[ic[0]], f.depth, 0, false}); continue; }
+        }
+        if (f.stage == 1) {
+            if (!ic.empty()) { emit(OP_MATVEC, 0, 0, ic[0]); f.started = true; }
+            for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
+                const int b = ix[idx];
+                if (ip[b + 1] > ip[b]) continue;
+                const int t = (int)h->tip_edge.size();
+                h->tip_edge.push_back(idx);
+                /* fused kernel reads codes through staged rows; generic reads the node directly */
+                emit(f.started ? OP_TIP_MUL : OP_TIP_SET, t, b, idx);
+                obs(b);
+                f.started = true;
+            }
+            f.stage = 2;
+        }
+        if (f.stage >= 2) {
+            const int i = f.stage - 1; /* next internal child index (>= 1) */
+            if (f.stage > 2) { /* returning from child i-1 */
+                emit(OP_MATVEC, 0, 0, ic[i - 1]);
+                emit(OP_POPMUL, 0, f.depth, -1);
+            }
+            if (i < (int)ic.size()) {
+                emit(OP_PUSH, 0, f.depth, -1);
+                f.stage++;
+                const int child = ix[ic[i]];
+                const int depth = f.depth + 1;
+                stk.push_back({child, depth, 0, false});
+                continue;
+            }
+            if (h->node_has_data[a]) { emit(OP_NODE_MUL, 0, a, -1); obs(a); }
+            if (scale_here[a]) emit(OP_SCALE, 0, 0, -1);
+            stk.pop_back();
+        }
+    }
+    h->prog_dirty = false;
+    h->stream_dirty = true;
+    return PLK_OK;
+}
+
+static bool use_fused(const plk_engine *h)
+{
+    if (h->opt_force_generic) return false;
+    if (h->k != 4 || h->pat_mode != 1) return false;
+    if (h->slots_needed > PLK_FUSED_SLOTS) return false;
+    const size_t lds = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE;
+    return lds <= 60 * 1024;
+}
+
+/* upload the program and (re)build the matrix stream / tip tables */
+static int prepare_stream(plk_engine *h, bool fused)
+{
+    int rc;
+    const int nops = (int)h->ops.size();
+    const int K = h->K, C = h->C;
+    if (!h->d_ops || h->stream_dirty) {
+        /* fused kernel addresses staged code rows, generic addresses nodes */
+        std::vector<int2> ops = h->ops;
+        if (fused) {
+            std::vector<int> row(h->N, -1);
+            for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
+            for (auto &o : ops) {
+                int code = o.x & 0xff;
+                if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) o.y = row[o.y];
+            }
+        }
+        if ((rc = dev_upload(h, &h->d_ops, ops.data(), ops.size()))) return rc;
+        if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
+        if ((rc = dev_upload(h, &h->d_tip_edge, h->tip_edge.data(), h->tip_edge.size()))) return rc;
+        if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
+    }
+    if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;
+    hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
+                       h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
+    HIPCHK(h, hipGetLastError());
+    if (fused) {
+        const int ntips = (int)h->tip_edge.size();
+        if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)C * ntips * h->nchar * 4))) return rc;
+        hipLaunchKernelGGL(k_build_tip, dim3(ntips, C), dim3(64), 0, h->stream,
+                           h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+        HIPCHK(h, hipGetLastError());
+    }
+    h->stream_dirty = false;
+    return PLK_OK;
+}
+
+template <int D>
+static void launch_fused(plk_engine *h, const FusedArgs &a, unsigned grid, size_t lds)
+{
+    hipLaunchKernelGGL(k_ll_fused4<D>, dim3(grid), dim3(PLK_TILE), lds, h->stream, a);
+}
+
+template <int K>
+static void launch_generic(plk_engine *h, const GenArgs &a, unsigned grid)
+{
+    hipLaunchKernelGGL(k_ll_generic<K>, dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+}
+
+extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_ll: tree, model and patterns must be set"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
+    const bool fused = use_fused(h);
+    if (h->stream_dirty || (long)(fused ? 1 : 2) != h->info_ll_kernel) {
+        h->stream_dirty = true;
+        if ((rc = prepare_stream(h, fused))) return rc;
+    }
+    const long S = h->S;
+    double *d_out = nullptr;
+    if (site_ll_out) {
+        if (where == PLK_DEVICE) d_out = site_ll_out;
+        else { if ((rc = dev_reserve(h, &h->d_site_ll, &h->site_ll_cap, (size_t)S))) return rc; d_out = h->d_site_ll; }
+    }
+    unsigned grid;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    if (fused) {
+        grid = (unsigned)((S + PLK_TILE - 1) / PLK_TILE);
+        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        FusedArgs a;
+        a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size();
+        a.ntips = (int)h->tip_edge.size(); a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
+        a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS; a.tip = h->d_tip;
+        a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
+        a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
+        a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE;
+        if (h->slots_needed <= 4) launch_fused<4>(h, a, grid, lds);
+        else if (h->slots_needed <= 8) launch_fused<8>(h, a, grid, lds);
+        else launch_fused<PLK_FUSED_SLOTS>(h, a, grid, lds);
+        h->info_ll_kernel = 1;
+    } else {
+        grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);
+        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        const int nslots = std::max(h->slots_needed, 1);
+        if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * h->k * S))) return rc;
+        GenArgs a;
+        a.S = S; a.Spad = h->Spad; a.k = h->k; a.C = h->C; a.nops = (int)h->ops.size(); a.nchar = h->nchar;
+        a.pat_mode = h->pat_mode; a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS;
+        a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B; a.cat_prior = h->d_cat_prior;
+        a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
+        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        switch (h->K) {
+        case 2: launch_generic<2>(h, a, grid); break;
+        case 4: launch_generic<4>(h, a, grid); break;
+        case 8: launch_generic<8>(h, a, grid); break;
+        case 16: launch_generic<16>(h, a, grid); break;
+        case 20: launch_generic<20>(h, a, grid); break;
+        case 32: launch_generic<32>(h, a, grid); break;
+        case 61: launch_generic<61>(h, a, grid); break;
+        default: launch_generic<64>(h, a, grid); break;
+        }
+        h->info_ll_kernel = 2;
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev2, h->stream));
+    if (sum_out) {
+        hipLaunchKernelGGL(k_dd_final, dim3(1), dim3(256), 0, h->stream, (int)grid, h->d_partial + 4, h->d_partial);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev3, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms_k = 0, ms_t = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms_k, h->ev1, h->ev2));
+    HIPCHK(h, hipEventElapsedTime(&ms_t, h->ev0, h->ev3));
+    h->info_ll_kernel_ns = (long)(ms_k * 1e6);
+    h->info_ll_total_ns = (long)(ms_t * 1e6);
+    if (sum_out) {
+        dd r;
+        HIPCHK(h, hipMemcpy(&r, h->d_partial, sizeof(dd), hipMemcpyDeviceToHost));
+        sum_out[0] = r.hi; sum_out[1] = r.lo;
+    }
+    if (site_ll_out && where != PLK_DEVICE)
+        HIPCHK(h, hipMemcpy(site_ll_out, h->d_site_ll, (size_t)S * sizeof(double), hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_out, double *edge_sums_out)
+{
+    (void)edge_mask; (void)site_edge_out; (void)edge_sums_out;
+    if (!h) return PLK_E_ARG;
+    h->err = "plk_deriv: not implemented yet";
+    return PLK_E_UNSUPPORTED;
+}
+
+extern "C" int plk_marginal(plk_engine *h, const int *node_mask, double *site_out, double *sums_out)
+{
+    (void)node_mask; (void)site_out; (void)sums_out;
+    if (!h) return PLK_E_ARG;
+    h->err = "plk_marginal: not implemented yet";
+    return PLK_E_UNSUPPORTED;
+}

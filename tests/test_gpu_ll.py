@@ -1,0 +1,107 @@
+"""GPU parity tests of the ll hot path (plk_* C-ABI) against the CPU oracle.
+
+Tolerance: per-site |ll_gpu - ll_oracle| <= 1e-12 * max(1, |ll_oracle|)
+(the fp64 tolerance BASELINE.json's north_star states)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_site_ll, oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from phyly_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _workload(cfg):
+    from phyly_amd import synth
+    return synth.Workload(cfg)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_transition_matrices_match_oracle(eng, oracle, cfg):
+    w = _workload(cfg)
+    w.setup_engine(eng)
+    P = eng.transition_matrices()
+    codes = w.simulate(4)
+    m, ow = oracle_model(oracle, w, codes)
+    assert P.shape == ow["P"].shape
+    # entries of P are probabilities: absolute tolerance relative to 1
+    assert np.max(np.abs(P - ow["P"])) <= 4e-16
+    np.testing.assert_allclose(P.sum(axis=-1), 1.0, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("cfg,S", [(2, 3000), (3, 3000), (4, 700), (5, 300)])
+@pytest.mark.parametrize("kind", ["simulated", "random"])
+def test_site_ll_matches_oracle(eng, oracle, cfg, S, kind):
+    from phyly_amd import engine as E
+    w = _workload(cfg)
+    w.setup_engine(eng)
+    codes = w.simulate(S) if kind == "simulated" else w.random_codes(S, seed=cfg)
+    want = oracle_site_ll(oracle, w, codes)
+    eng.set_option(E.OPT_FORCE_GENERIC, 0)
+    eng.set_patterns_codes(codes, w.defs)
+    got, (hi, lo) = eng.ll()
+    kernel = eng.info(E.INFO_LL_KERNEL)
+    assert kernel == (1 if w.k == 4 else 2)
+    assert rel_err(got, want) <= TOL
+    assert abs((hi + lo) - float(np.sum(want.astype(np.longdouble)))) <= TOL * abs(np.sum(want))
+    # the generic (HBM-slot) traversal must agree too
+    eng.set_option(E.OPT_FORCE_GENERIC, 1)
+    got2, _ = eng.ll()
+    assert eng.info(E.INFO_LL_KERNEL) == 2
+    assert rel_err(got2, want) <= TOL
+    eng.set_option(E.OPT_FORCE_GENERIC, 0)
+
+
+def test_ragged_sizes_and_weights(eng, oracle):
+    """S not a multiple of the 256-site tile; weighted sums; S = 1."""
+    w = _workload(3)
+    w.setup_engine(eng)
+    for S in (1, 63, 257, 1000):
+        codes = w.simulate(S)
+        want = oracle_site_ll(oracle, w, codes)
+        eng.set_patterns_codes(codes, w.defs)
+        wts = np.linspace(0.5, 2.0, S)
+        eng.set_site_weights(wts)
+        got, (hi, lo) = eng.ll()
+        assert rel_err(got, want) <= TOL
+        ref = float(np.sum(want.astype(np.longdouble) * wts.astype(np.longdouble)))
+        assert abs((hi + lo) - ref) <= TOL * max(1.0, abs(ref))
+
+
+def test_dense_patterns_generic_kernel(eng, oracle):
+    """probability_array-style dense observations B[N][k][S] with data on internal nodes."""
+    w = _workload(2)
+    w.setup_engine(eng)
+    S = 200
+    rng = np.random.default_rng(5)
+    B = rng.random((S, w.N, w.k))            # oracle layout [S][N][k]
+    B[:, ::3, :] = 1.0                        # some nodes unobserved
+    m, ow = oracle_model(oracle, w, w.simulate(1))
+    want, _ = oracle.site_ll(m, ow, B=B)
+    eng.set_patterns_dense(np.ascontiguousarray(B.transpose(1, 2, 0)))
+    got, _ = eng.ll()
+    assert rel_err(got, want) <= TOL
+
+
+def test_deep_scaling_no_underflow(eng, oracle):
+    """A 400-taxon caterpillar-ish random tree with random data: site likelihoods
+    around 1e-250..1e-400 must not underflow (exact power-of-two rescaling)."""
+    from phyly_amd import synth
+    w = synth.Workload(T=600, k=4, tree="yule", model="gtr_g4", seed=77)
+    w.setup_engine(eng)
+    codes = w.random_codes(500, seed=3, missing_frac=0.0)
+    want = oracle_site_ll(oracle, w, codes)
+    assert want.min() < -700          # below the fp64 underflow threshold in linear space
+    eng.set_patterns_codes(codes, w.defs)
+    got, _ = eng.ll()
+    assert np.all(np.isfinite(got))
+    assert rel_err(got, want) <= TOL
