@@ -81,9 +81,13 @@ int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *indices,
 /* Model: k states, C rate categories.
  * Qn[k*k] row-major: rate matrix already divided by the rate divisor, with
  * its diagonal set to minus the row sums (src/cross_site_ws.c:217-232).
+ * Qn_lo[k*k] (may be NULL = zeros): low-order words, Qn + Qn_lo being the
+ * normalised matrix to ~106 bits; the reference normalises in exact ball
+ * arithmetic, and d/dt exp(Qt) = Q exp(Qt) at long branches is only as accurate
+ * as the zero row sums of Q (examples/JC.long.branch of the reference).
  * edge_rates_csr[E], cat_rates[C], cat_prior[C], root_w[k] (ignored for
  * NONE/UNIFORM).  Runs the device exp(Q r t) kernel for all (c, e). */
-int plk_set_model(plk_engine *h, int k, int C, const double *Qn,
+int plk_set_model(plk_engine *h, int k, int C, const double *Qn, const double *Qn_lo,
                   const double *edge_rates_csr,
                   const double *cat_rates, const double *cat_prior,
                   int root_mode, const double *root_w);

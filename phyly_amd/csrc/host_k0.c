@@ -4,8 +4,10 @@
  * Product code (host C).  Turns the user's raw rate matrix, rate divisor, root
  * prior and rate-mixture description into what the device engine consumes
  * (plk_set_model): the normalised rate matrix Qn, category rates and priors,
- * and the stationary distribution.  Evaluated in long double and rounded
- * once to double; P = exp(Qn r t) itself is computed on the GPU.
+ * and the stationary distribution.  Evaluated in IEEE binary128 (__float128,
+ * libquadmath) and rounded once; the normalised matrix is handed over as a
+ * double-double (hi, lo) pair so that its rows sum to zero to ~1e-32.
+ * P = exp(Qn r t) itself is computed on the GPU.
  *
  * Follows the order of operations of the reference
  * (paths relative to argriffing/phyly):
@@ -16,27 +18,28 @@
  *   src/gamma_discretization.c:209-370          quantiles and mean / median rates
  */
 #include <math.h>
+#include <quadmath.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "host_k0.h"
 
-typedef long double ld;
+typedef __float128 ld;
 
 /* regularised lower incomplete gamma P(s, x), all-positive series:
  * P = x^s e^-x / Gamma(s+1) * sum_{n>=0} x^n / ((s+1)...(s+n)) */
 static ld gamma_p(ld s, ld x)
 {
     if (!(x > 0)) return 0;
-    if (isinf(x)) return 1;
-    ld lead = s * logl(x) - x - lgammal(s + 1);
+    if (isinfq(x)) return 1;
+    ld lead = s * logq(x) - x - lgammaq(s + 1);
     ld term = 1, sum = 1;
     for (int n = 1; n < 200000; n++) {
         term *= x / (s + n);
         sum += term;
-        if (term < sum * 1e-22L) break;
+        if (term < sum * 1e-36Q) break;
     }
-    ld r = expl(lead) * sum;
+    ld r = expq(lead) * sum;
     return r > 1 ? 1 : r;
 }
 
@@ -44,18 +47,18 @@ static ld gamma_p(ld s, ld x)
 static ld gamma_quantile(ld s, ld p)
 {
     ld lo = -16000, hi = 16000;
-    if (gamma_p(s, ldexpl(1.0L, (int)lo)) >= p) return 0;
-    for (int it = 0; it < 120; it++) {
-        ld mid = 0.5L * (lo + hi);
-        if (gamma_p(s, exp2l(mid)) < p) lo = mid; else hi = mid;
+    if (gamma_p(s, ldexpq(1.0Q, (int)lo)) >= p) return 0;
+    for (int it = 0; it < 200; it++) {
+        ld mid = 0.5Q * (lo + hi);
+        if (gamma_p(s, exp2q(mid)) < p) lo = mid; else hi = mid;
     }
-    ld a = exp2l(lo), b = exp2l(hi);
-    for (int it = 0; it < 120; it++) {
-        ld m = 0.5L * (a + b);
+    ld a = exp2q(lo), b = exp2q(hi);
+    for (int it = 0; it < 200; it++) {
+        ld m = 0.5Q * (a + b);
         if (m <= a || m >= b) break;
         if (gamma_p(s, m) < p) a = m; else b = m;
     }
-    return 0.5L * (a + b);
+    return 0.5Q * (a + b);
 }
 
 static void gamma_rates(int mode, int n, ld shape, ld *rates)
@@ -96,8 +99,8 @@ static int equilibrium(int k, const ld *Q, ld *pi)
     int ok = 0;
     for (int c = 0; c < n; c++) {
         int p = c;
-        ld best = fabsl(R[c * w + c]);
-        for (int r = c + 1; r < n; r++) if (fabsl(R[r * w + c]) > best) { best = fabsl(R[r * w + c]); p = r; }
+        ld best = fabsq(R[c * w + c]);
+        for (int r = c + 1; r < n; r++) if (fabsq(R[r * w + c]) > best) { best = fabsq(R[r * w + c]); p = r; }
         if (best == 0) { ok = -1; break; }
         if (p != c) for (int j = 0; j < w; j++) { ld t = R[c * w + j]; R[c * w + j] = R[p * w + j]; R[p * w + j] = t; }
         for (int r = 0; r < n; r++) {
@@ -106,7 +109,7 @@ static int equilibrium(int k, const ld *Q, ld *pi)
             if (f != 0) for (int j = c; j < w; j++) R[r * w + j] -= f * R[c * w + j];
         }
     }
-    for (int i = 0; i < k; i++) pi[i] = ok ? NAN : R[i * w + n] / R[i * w + i];
+    for (int i = 0; i < k; i++) pi[i] = ok ? (ld)NAN : R[i * w + n] / R[i * w + i];
     free(R);
     return ok;
 }
@@ -121,7 +124,7 @@ int arbplf_k0_category_count(const k0_mixture *mix)
 int arbplf_k0_prepare(int k, const double *rate_matrix,
                       int use_equilibrium_divisor, double divisor_value, int need_equilibrium,
                       const k0_mixture *mix,
-                      double *cat_rates, double *cat_prior, double *pi_out, double *Qn_out)
+                      double *cat_rates, double *cat_prior, double *pi_out, double *Qn_out, double *Qn_lo_out)
 {
     const int C = arbplf_k0_category_count(mix);
     ld expect = 1;
@@ -134,7 +137,7 @@ int arbplf_k0_prepare(int k, const double *rate_matrix,
         for (int i = 0; i < C; i++) { rates[i] = mix->rates[i]; cat_prior[i] = mix->prior[i]; expect += (ld)mix->rates[i] * (ld)mix->prior[i]; }
     } else if (mix->mode == K0_MIX_UNIFORM) {
         expect = 0;
-        for (int i = 0; i < C; i++) { rates[i] = mix->rates[i]; cat_prior[i] = (double)(1.0L / (ld)C); expect += (ld)mix->rates[i]; }
+        for (int i = 0; i < C; i++) { rates[i] = mix->rates[i]; cat_prior[i] = (double)(1.0Q / (ld)C); expect += (ld)mix->rates[i]; }
         expect /= C;
     } else {
         ld p = mix->invariable_prior, q = 1 - p;
@@ -167,7 +170,10 @@ int arbplf_k0_prepare(int k, const double *rate_matrix,
         for (int j = 0; j < k; j++) if (j != i) { Q[i * k + j] /= divisor; rs += Q[i * k + j]; }
         Q[i * k + i] = -rs;
     }
-    for (size_t i = 0; i < kk; i++) Qn_out[i] = (double)Q[i];
+    for (size_t i = 0; i < kk; i++) {
+        Qn_out[i] = (double)Q[i];
+        if (Qn_lo_out) Qn_lo_out[i] = (double)(Q[i] - (ld)Qn_out[i]);
+    }
     free(Q); free(pi);
     return C;
 }

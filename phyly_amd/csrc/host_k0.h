@@ -28,13 +28,14 @@ int arbplf_k0_category_count(const k0_mixture *mix);
 
 /*
  * rate_matrix[k*k] raw (diagonal ignored).  Outputs: cat_rates[C], cat_prior[C],
- * pi_out[k] (zeros unless need_equilibrium), Qn_out[k*k] normalised with diagonal.
+ * pi_out[k] (zeros unless need_equilibrium), Qn_out[k*k] normalised with diagonal,
+ * Qn_lo_out[k*k] (may be NULL) its low-order double-double words.
  * Returns C (>= 1) or -1 on allocation failure.
  */
 int arbplf_k0_prepare(int k, const double *rate_matrix,
                       int use_equilibrium_divisor, double divisor_value, int need_equilibrium,
                       const k0_mixture *mix,
-                      double *cat_rates, double *cat_prior, double *pi_out, double *Qn_out);
+                      double *cat_rates, double *cat_prior, double *pi_out, double *Qn_out, double *Qn_lo_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,388 @@
+/*
+ * host_model.c -- JSON -> host_model validation (host C, product code).
+ *
+ * Reproduces which inputs the reference accepts and rejects
+ * (src/parsemodel.c, src/parsereduction.c, src/csr_graph.c), with our own
+ * diagnostics on stderr.  Behaviours the reference leaves unpinned
+ *  are rejected: non-positive gamma_categories / gamma_shape,
+ * invariable_prior outside [0, 1), a rate_mixture prior that is neither a
+ * string nor an array, an empty alignment.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "host_model.h"
+
+static int exists(const jval *v) { return v && !j_is_null(v); }
+
+#define FAILF(...) do { fprintf(stderr, __VA_ARGS__); return -1; } while (0)
+
+int host_check_keys(const jval *obj, const char *const *required, const char *const *allowed, const char *what)
+{
+    if (!j_is_object(obj)) FAILF("error: %s: expected an object\n", what);
+    for (size_t i = 0; i < j_len(obj); i++) {
+        const char *key = obj->u.c.keys[i];
+        int ok = 0;
+        for (const char *const *a = allowed; *a; a++) if (!strcmp(*a, key)) ok = 1;
+        if (!ok) FAILF("error: %s: unexpected key \"%s\"\n", what, key);
+    }
+    for (const char *const *r = required; *r; r++)
+        if (!j_get(obj, *r)) FAILF("error: %s: missing key \"%s\"\n", what, *r);
+    return 0;
+}
+
+/* src/parsemodel.c:26-75 */
+static int nonneg_array(double *dest, int n, const jval *a, const char *what)
+{
+    if (!j_is_array(a)) FAILF("%s: not an array\n", what);
+    if ((int)j_len(a) != n) FAILF("%s: unexpected array length (actual: %d desired: %d)\n", what, (int)j_len(a), n);
+    for (int i = 0; i < n; i++) {
+        const jval *x = j_at(a, i);
+        if (!j_is_number(x)) FAILF("%s: not a number\n", what);
+        double d = j_number(x);
+        if (d < 0) FAILF("%s: array entries must be nonnegative\n", what);
+        dest[i] = d;
+    }
+    return 0;
+}
+
+void host_model_init(host_model *m) { memset(m, 0, sizeof(*m)); m->rate_divisor = 1.0; m->mix.mode = K0_MIX_NONE; m->mix.n = 1; }
+
+void host_model_clear(host_model *m)
+{
+    free(m->indptr); free(m->indices); free(m->preorder); free(m->edge_order); free(m->csr_to_user);
+    free(m->edge_rates_user); free(m->edge_rates_csr); free(m->rate_matrix); free(m->root_custom);
+    free(m->mix_rates); free(m->mix_prior); free(m->prob); free(m->codes8); free(m->defs);
+    memset(m, 0, sizeof(*m));
+}
+
+/* src/parsemodel.c:211-368 + src/csr_graph.c:103-229 */
+static int parse_edges(host_model *m, const jval *edges)
+{
+    if (!j_is_array(edges)) FAILF("_validate_edges: not an array\n");
+    const int E = (int)j_len(edges), N = E + 1;
+    int rc = -1;
+    int *indeg = calloc(N, sizeof(int)), *outdeg = calloc(N, sizeof(int));
+    int *pa = malloc((E + 1) * sizeof(int)), *pb = malloc((E + 1) * sizeof(int));
+    int *fill = NULL, *visited = NULL;
+    if (!indeg || !outdeg || !pa || !pb) goto done;
+    for (int i = 0; i < E; i++) {
+        const jval *e = j_at(edges, i);
+        if (!j_is_array(e) || j_len(e) != 2 || !j_is_int(j_at(e, 0)) || !j_is_int(j_at(e, 1))) {
+            fprintf(stderr, "_validate_edges: each edge must be an array of two integers\n"); goto done;
+        }
+        long long a = j_at(e, 0)->u.i, b = j_at(e, 1)->u.i;
+        if (a < 0 || a >= N || b < 0 || b >= N) {
+            fprintf(stderr, "_validate_edges: node indices must be integers no less than 0 and no greater than the number of edges\n"); goto done;
+        }
+        if (a == b) { fprintf(stderr, "_validate_edges: edges cannot be loops\n"); goto done; }
+        pa[i] = (int)a; pb[i] = (int)b;
+        outdeg[a]++; indeg[b]++;
+    }
+    int root = -1, roots = 0;
+    for (int i = 0; i < N; i++) if (!indeg[i]) { root = i; roots++; }
+    if (roots != 1) { fprintf(stderr, "_validate_edges: exactly one node should have in-degree 0\n"); goto done; }
+    for (int i = 0; i < N; i++) if (indeg[i] > 1) { fprintf(stderr, "_validate_edges: the in-degree of each node must be 0 or 1\n"); goto done; }
+    for (int i = 0; i < N; i++) if (indeg[i] + outdeg[i] < 1) { fprintf(stderr, "_validate_edges: node index %d is not an endpoint of any edge\n", i); goto done; }
+    m->N = N; m->E = E; m->root = root;
+    m->indptr = malloc((N + 1) * sizeof(int));
+    m->indices = malloc((E + 1) * sizeof(int));
+    m->preorder = malloc(N * sizeof(int));
+    m->edge_order = malloc((E + 1) * sizeof(int));
+    m->csr_to_user = malloc((E + 1) * sizeof(int));
+    fill = calloc(N, sizeof(int));
+    visited = calloc(N, sizeof(int));
+    if (!m->indptr || !m->indices || !m->preorder || !m->edge_order || !m->csr_to_user || !fill || !visited) goto done;
+    m->indptr[0] = 0;
+    for (int i = 0; i < N; i++) m->indptr[i + 1] = m->indptr[i] + outdeg[i];
+    for (int i = 0; i < E; i++) {
+        int pos = m->indptr[pa[i]] + fill[pa[i]]++;
+        m->indices[pos] = pb[i];
+        m->edge_order[i] = pos;
+        m->csr_to_user[pos] = i;
+    }
+    /* BFS by levels from the root; must reach every node exactly once */
+    int npre = 0, head = 0;
+    m->preorder[npre++] = root; visited[root] = 1;
+    while (head < npre) {
+        int a = m->preorder[head++];
+        for (int j = m->indptr[a]; j < m->indptr[a + 1]; j++) {
+            int b = m->indices[j];
+            if (visited[b]) { fprintf(stderr, "validate_edges: topo sort failed: node index %d already visited\n", b); goto done; }
+            visited[b] = 1;
+            m->preorder[npre++] = b;
+        }
+    }
+    if (npre != N) { fprintf(stderr, "validate_edges: the topo sort contains %d of the %d nodes\n", npre, N); goto done; }
+    rc = 0;
+done:
+    free(indeg); free(outdeg); free(pa); free(pb); free(fill); free(visited);
+    return rc;
+}
+
+static int parse_rate_matrix(host_model *m, const jval *rm)
+{
+    if (!j_is_array(rm)) FAILF("_validate_rate_matrix: not an array\n");
+    const int k = (int)j_len(rm);
+    m->k = k;
+    m->rate_matrix = malloc((size_t)(k ? k : 1) * (k ? k : 1) * sizeof(double));
+    if (!m->rate_matrix) return -1;
+    for (int i = 0; i < k; i++) {
+        const jval *row = j_at(rm, i);
+        if (!j_is_array(row)) FAILF("_validate_rate_matrix: this row is not an array\n");
+        if ((int)j_len(row) != k) FAILF("_validate_rate_matrix: this row length does not match the number of rows: (actual: %d desired: %d)\n", (int)j_len(row), k);
+        for (int j = 0; j < k; j++) {
+            const jval *y = j_at(row, j);
+            if (!j_is_number(y)) FAILF("_validate_rate_matrix: not a number\n");
+            double d = j_number(y);
+            if (d < 0) FAILF("_validate_rate_matrix: rate matrix entries must be nonnegative\n");
+            m->rate_matrix[(size_t)i * k + j] = d;
+        }
+    }
+    if (k < 1) FAILF("_validate_rate_matrix: the rate matrix is empty\n");
+    return 0;
+}
+
+static int parse_probability_array(host_model *m, const jval *pa)
+{
+    const char *name = "_validate_probability_array";
+    if (!j_is_array(pa)) FAILF("%s: expected an array\n", name);
+    const long S = (long)j_len(pa);
+    const int N = m->N, k = m->k;
+    m->S = S;
+    m->prob = malloc(((size_t)S * N * k + 1) * sizeof(double));
+    if (!m->prob) return -1;
+    for (long s = 0; s < S; s++) {
+        const jval *x = j_at(pa, s);
+        if (!j_is_array(x)) FAILF("%s: expected an array\n", name);
+        if ((int)j_len(x) != N) FAILF("%s: failed to match the number of nodes: (actual: %d desired: %d)\n", name, (int)j_len(x), N);
+        for (int a = 0; a < N; a++)
+            if (nonneg_array(m->prob + ((size_t)s * N + a) * k, k, j_at(x, a), name)) return -1;
+    }
+    return 0;
+}
+
+/* src/parsemodel.c:515-628 */
+static int parse_character_data(host_model *m, const jval *cd, const jval *defs)
+{
+    const char *name = "_validate_character_data_and_definitions";
+    if (!exists(defs)) fprintf(stderr, "%s: 'character_data' has been provided without 'character_definitions'\n", name);
+    if (!j_is_array(cd)) FAILF("%s: expected 'character_data' to be an array\n", name);
+    if (!j_is_array(defs)) FAILF("%s: expected 'character_definitions' to be an array\n", name);
+    const long S = (long)j_len(cd);
+    const int N = m->N, k = m->k, nchar = (int)j_len(defs);
+    m->S = S; m->nchar = nchar;
+    m->defs = malloc(((size_t)nchar * k + 1) * sizeof(double));
+    if (!m->defs) return -1;
+    for (int c = 0; c < nchar; c++)
+        if (nonneg_array(m->defs + (size_t)c * k, k, j_at(defs, c), name)) return -1;
+    const int compact = nchar <= 256;
+    if (compact) m->codes8 = malloc((size_t)S * N + 1);
+    else m->prob = malloc(((size_t)S * N * k + 1) * sizeof(double));
+    if (!m->codes8 && !m->prob) return -1;
+    for (long s = 0; s < S; s++) {
+        const jval *x = j_at(cd, s);
+        if (!j_is_array(x)) FAILF("%s: expected an array\n", name);
+        if ((int)j_len(x) != N) FAILF("%s: failed to match the number of nodes: (actual: %d desired: %d)\n", name, (int)j_len(x), N);
+        for (int a = 0; a < N; a++) {
+            const jval *y = j_at(x, a);
+            if (!j_is_int(y)) FAILF("%s: character indices must be integers\n", name);
+            long long c = y->u.i;
+            if (c < 0) FAILF("%s: character indices must be non-negative\n", name);
+            if (c >= nchar) FAILF("%s: character indices must each be less than the character count (%d)\n", name, nchar);
+            if (compact) m->codes8[(size_t)s * N + a] = (uint8_t)c;
+            else memcpy(m->prob + ((size_t)s * N + a) * k, m->defs + (size_t)c * k, k * sizeof(double));
+        }
+    }
+    if (!compact) { free(m->defs); m->defs = NULL; m->nchar = 0; }
+    return 0;
+}
+
+static int parse_rate_divisor(host_model *m, const jval *rd)
+{
+    const char *msg = "_validate_rate_divisor: the optional rate_divisor argument must be either a positive number "
+                      "or the string \"equilibrium_exit_rate\"\n";
+    if (!exists(rd)) return 0;
+    if (j_is_string(rd)) {
+        if (strcmp(rd->u.s, "equilibrium_exit_rate")) FAILF("%s", msg);
+        m->use_equilibrium_divisor = 1;
+    } else if (j_is_number(rd)) {
+        double d = j_number(rd);
+        if (!(d > 0)) FAILF("%s", msg);
+        m->rate_divisor = d;
+    } else FAILF("%s", msg);
+    return 0;
+}
+
+static int parse_root_prior(host_model *m, const jval *rp)
+{
+    const char *msg = "_validate_root_prior: the optional \"root_prior\" must be either a list of probabilities or one "
+                      "of the strings {\"equilibrium_distribution\", \"uniform_distribution\"}\n";
+    if (!exists(rp)) { m->root_mode = HM_ROOT_NONE; return 0; }
+    if (j_is_string(rp)) {
+        if (!strcmp(rp->u.s, "equilibrium_distribution")) m->root_mode = HM_ROOT_EQUILIBRIUM;
+        else if (!strcmp(rp->u.s, "uniform_distribution")) m->root_mode = HM_ROOT_UNIFORM;
+        else FAILF("%s", msg);
+        return 0;
+    }
+    m->root_mode = HM_ROOT_CUSTOM;
+    m->root_custom = malloc((size_t)m->k * sizeof(double));
+    if (!m->root_custom) return -1;
+    if (nonneg_array(m->root_custom, m->k, rp, "_validate_root_prior")) FAILF("%s", msg);
+    return 0;
+}
+
+/* src/parsemodel.c:632-713 */
+static int parse_rate_mixture(host_model *m, const jval *rm)
+{
+    static const char *const req[] = {"rates", "prior", NULL};
+    if (host_check_keys(rm, req, req, "rate_mixture")) return -1;
+    const jval *rates = j_get(rm, "rates"), *prior = j_get(rm, "prior");
+    if (!j_is_array(rates)) FAILF("_validate_rate_mixture: 'rates' is not an array\n");
+    const int n = (int)j_len(rates);
+    if (n < 1) FAILF("_validate_rate_mixture: empty mixture\n");
+    m->mix_rates = malloc(n * sizeof(double));
+    m->mix_prior = calloc(n, sizeof(double));
+    if (!m->mix_rates || !m->mix_prior) return -1;
+    if (nonneg_array(m->mix_rates, n, rates, "_validate_rate_mixture")) FAILF("_validate_rate_mixture: invalid 'rates' array\n");
+    if (j_is_string(prior)) {
+        if (strcmp(prior->u.s, "uniform_distribution"))
+            FAILF("_validate_rate_mixture: the 'prior' argument must be either a nonnegative array or the string \"uniform_distribution\"\n");
+        m->mix.mode = K0_MIX_UNIFORM;
+    } else if (j_is_array(prior)) {
+        if (nonneg_array(m->mix_prior, n, prior, "_validate_rate_mixture")) FAILF("_validate_rate_mixture: invalid 'prior' array\n");
+        m->mix.mode = K0_MIX_CUSTOM;
+    } else FAILF("_validate_rate_mixture: the 'prior' argument must be either a nonnegative array or the string \"uniform_distribution\"\n");
+    m->mix.n = n; m->mix.rates = m->mix_rates; m->mix.prior = m->mix_prior;
+    return 0;
+}
+
+/* src/parsemodel.c:716-783 */
+static int parse_gamma_mixture(host_model *m, const jval *g, int mode)
+{
+    static const char *const req[] = {"gamma_shape", "gamma_categories", NULL};
+    static const char *const all[] = {"gamma_shape", "gamma_categories", "invariable_prior", NULL};
+    if (host_check_keys(g, req, all, "gamma rate mixture")) return -1;
+    const jval *ip = j_get(g, "invariable_prior"), *gs = j_get(g, "gamma_shape"), *gc = j_get(g, "gamma_categories");
+    m->mix.mode = mode;
+    m->mix.invariable_prior = 0;
+    if (exists(ip)) {
+        if (!j_is_number(ip)) FAILF("invariable_prior: not a number\n");
+        m->mix.invariable_prior = j_number(ip);
+    }
+    if (!j_is_number(gs)) FAILF("gamma_shape: not a number\n");
+    m->mix.gamma_shape = j_number(gs);
+    if (!j_is_int(gc)) FAILF("gamma_categories: not an integer\n");
+    if (gc->u.i < 1 || gc->u.i > 1000000) FAILF("gamma_categories: must be a positive integer\n");
+    m->mix.n = (int)gc->u.i;
+    if (!(m->mix.gamma_shape > 0)) FAILF("gamma_shape: must be positive\n");
+    if (!(m->mix.invariable_prior >= 0 && m->mix.invariable_prior < 1)) FAILF("invariable_prior: must be in [0, 1)\n");
+    return 0;
+}
+
+/* src/parsemodel.c:786-913 */
+int host_model_parse(host_model *m, const jval *root)
+{
+    static const char *const req[] = {"edges", "edge_rate_coefficients", "rate_matrix", NULL};
+    static const char *const all[] = {"edges", "edge_rate_coefficients", "rate_matrix", "probability_array",
+        "character_definitions", "character_data", "rate_divisor", "root_prior", "rate_mixture",
+        "gamma_rate_mixture", "normalized_median_gamma_rate_mixture", NULL};
+    if (host_check_keys(root, req, all, "model_and_data")) return -1;
+    const jval *pa = j_get(root, "probability_array"), *cdefs = j_get(root, "character_definitions");
+    const jval *cdata = j_get(root, "character_data"), *rmix = j_get(root, "rate_mixture");
+    const jval *gmix = j_get(root, "gamma_rate_mixture"), *gmed = j_get(root, "normalized_median_gamma_rate_mixture");
+    if (exists(rmix) + exists(gmix) + exists(gmed) > 1) FAILF("error: conflicting rate mixture options\n");
+    if (exists(pa) && exists(cdata)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_data' have both been specified\n");
+    if (exists(pa) && exists(cdefs)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_definitions' have both been specified\n");
+
+    if (parse_edges(m, j_get(root, "edges"))) return -1;
+    m->edge_rates_user = malloc((size_t)(m->E + 1) * sizeof(double));
+    m->edge_rates_csr = malloc((size_t)(m->E + 1) * sizeof(double));
+    if (!m->edge_rates_user || !m->edge_rates_csr) return -1;
+    if (nonneg_array(m->edge_rates_user, m->E, j_get(root, "edge_rate_coefficients"), "_validate_edge_rate_coefficients")) return -1;
+    for (int i = 0; i < m->E; i++) m->edge_rates_csr[m->edge_order[i]] = m->edge_rates_user[i];
+    if (parse_rate_matrix(m, j_get(root, "rate_matrix"))) return -1;
+    if (exists(pa)) { if (parse_probability_array(m, pa)) return -1; }
+    else if (exists(cdata)) { if (parse_character_data(m, cdata, cdefs)) return -1; }
+    else FAILF("error: either 'probability_array' or 'character_data' must be specified\n");
+    if (parse_rate_divisor(m, j_get(root, "rate_divisor"))) return -1;
+    if (parse_root_prior(m, j_get(root, "root_prior"))) return -1;
+    if (exists(gmix)) { if (parse_gamma_mixture(m, gmix, K0_MIX_GAMMA)) return -1; }
+    else if (exists(gmed)) { if (parse_gamma_mixture(m, gmed, K0_MIX_GAMMA_MEDIAN)) return -1; }
+    else if (exists(rmix)) { if (parse_rate_mixture(m, rmix)) return -1; }
+    else { m->mix.mode = K0_MIX_NONE; m->mix.n = 1; }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- reductions */
+void host_reduction_init(host_reduction *r) { memset(r, 0, sizeof(*r)); }
+void host_reduction_clear(host_reduction *r) { free(r->selection); free(r->weights); memset(r, 0, sizeof(*r)); }
+
+/* src/parsereduction.c:20-195 */
+int host_reduction_parse(host_reduction *r, int n, const char *name, const jval *root)
+{
+    static const char *const none[] = {NULL};
+    static const char *const all[] = {"selection", "aggregation", NULL};
+    const jval *sel = NULL, *agg = NULL;
+    r->n = n;
+    if (root) {
+        if (host_check_keys(root, none, all, "reduction")) return -1;
+        sel = j_get(root, "selection");
+        agg = j_get(root, "aggregation");
+    }
+    if (!sel) {
+        r->selection_len = n;
+        r->selection = malloc((size_t)(n + 1) * sizeof(int));
+        if (!r->selection) return -1;
+        for (int i = 0; i < n; i++) r->selection[i] = i;
+    } else {
+        if (!j_is_array(sel)) FAILF("error: %s selection: the selection should be an array\n", name);
+        r->selection_len = (int)j_len(sel);
+        r->selection = malloc((size_t)(r->selection_len + 1) * sizeof(int));
+        if (!r->selection) return -1;
+        for (int i = 0; i < r->selection_len; i++) {
+            const jval *x = j_at(sel, i);
+            if (!j_is_int(x)) FAILF("error: %s selection: each index in the selection must be an integer\n", name);
+            if (x->u.i < 0) FAILF("error: %s selection: each index in the selection must be non-negative\n", name);
+            if (x->u.i >= n) FAILF("error: %s selection: each index in the selection must be less than the total number of available %s indices\n", name, name);
+            r->selection[i] = (int)x->u.i;
+        }
+    }
+    if (!agg) r->agg_mode = AGG_NONE;
+    else if (j_is_string(agg)) {
+        if (!strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
+        else if (!strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
+        else if (!strcmp(agg->u.s, "only")) {
+            if (r->selection_len != 1) FAILF("error: %s aggregation (\"only\"): the selection length must be exactly 1 (selection_len = %d)\n", name, r->selection_len);
+            r->agg_mode = AGG_ONLY;
+        } else FAILF("error: %s aggregation (string): the only valid aggregation strings are {\"sum\", \"avg\", \"only\"}\n", name);
+    } else if (j_is_array(agg)) {
+        r->agg_mode = AGG_WEIGHTED_SUM;
+        if ((int)j_len(agg) != r->selection_len) FAILF("error: %s aggregation (weighted sum): the number of weights must be equal to the number of selected %s indices\n", name, name);
+        r->weights = malloc((size_t)(r->selection_len + 1) * sizeof(double));
+        if (!r->weights) return -1;
+        for (int i = 0; i < r->selection_len; i++) {
+            const jval *x = j_at(agg, i);
+            if (!j_is_number(x)) FAILF("error: %s aggregation (weighted sum): weights should be numeric\n", name);
+            r->weights[i] = j_number(x);
+        }
+    } else FAILF("error: %s aggregation: if provided, the aggregation should be a string or an array of numeric weights\n", name);
+    if (r->agg_mode == AGG_AVG && r->selection_len == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
+    return 0;
+}
+
+/* src/reduction.c:25-118 */
+void host_reduction_weights(const host_reduction *r, long double *w, long double *divisor)
+{
+    for (int i = 0; i < r->n; i++) w[i] = 0;
+    *divisor = 1;
+    if (r->agg_mode == AGG_WEIGHTED_SUM) {
+        for (int i = 0; i < r->selection_len; i++) w[r->selection[i]] += (long double)r->weights[i];
+    } else if (r->agg_mode == AGG_SUM || r->agg_mode == AGG_AVG) {
+        for (int i = 0; i < r->selection_len; i++) w[r->selection[i]] += 1;
+        if (r->agg_mode == AGG_AVG) *divisor = r->selection_len;
+    } else if (r->agg_mode == AGG_ONLY) {
+        w[r->selection[0]] = 1;
+    }
+}

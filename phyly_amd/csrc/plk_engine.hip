@@ -178,7 +178,7 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 
 #define EXPM_TERMS 28
 
-__global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn,
+__global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn /* [2][k*k]: hi then lo */,
                           const double *__restrict__ edge_rates,
                           const double *__restrict__ cat_rates,
                           dd *__restrict__ Pdd, double *__restrict__ P, double *__restrict__ dP,
@@ -194,7 +194,7 @@ __global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn,
     dd *X = base, *T = base + kk, *O = base + 2 * kk, *W = base + 3 * kk;
 
     const dd s = dd_two_prod(cat_rates[c], edge_rates[e]);
-    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_mul_d(s, Qn[idx]);
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_mul(s, dd_make(Qn[idx], Qn[kk + idx]));
     __syncthreads();
     if ((int)threadIdx.x < k) {
         double r = 0;
@@ -244,7 +244,7 @@ __global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn,
         P[(size_t)ce * kk + idx] = v.hi;
         int i = idx / k, j = idx - i * k;
         dd acc = dd_make(0.0, 0.0);
-        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul_d(O[l * k + j], Qn[i * k + l]));
+        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(O[l * k + j], dd_make(Qn[i * k + l], Qn[kk + i * k + l])));
         acc = dd_mul_d(acc, rc);
         dP[(size_t)ce * kk + idx] = acc.hi;
     }
@@ -626,6 +626,292 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_ll_generic(GenArgs a)
 }
 
 /* ====================================================================== */
+/* K2 with stored vectors + K4/K5/K6 (up pass): deriv and marginal         */
+/* ====================================================================== */
+
+struct UpArgs {
+    long S, Spad;        /* full pattern extent (row pitch of codes / B) */
+    long s0, n;          /* chunk [s0, s0+n) */
+    int N, E, k, C, nchar, pat_mode, root_mode;
+    const int *indptr, *indices, *preorder;
+    const char *node_has_data;  /* N */
+    const double *PT;    /* [C][E][K*K] transposed P:  PT[j*K+i] = P[i][j]  */
+    const double *PN;    /* [C][E][K*K] plain P:       PN[i*K+j] = P[i][j]  */
+    const double *DT;    /* [C][E][K*K] transposed dP: DT[j*K+i] = dP[i][j] */
+    const uint8_t *codes;
+    const double *defs;  /* [nchar][K] */
+    const double *B;     /* [N][k][S] */
+    const double *cat_prior, *root_w;
+    const int *edge_mask, *node_mask;   /* device, may be null = all */
+    double *EV;          /* [E][C][k][n] */
+    double *LN;          /* [N][C][k][n] (internal nodes only are written) */
+    double *FN;          /* [N][C][k][n] */
+    double *LH;          /* [n] site likelihood */
+    double *DV;          /* [E][n] derivative values */
+    double *MV;          /* [N][k][n] marginal values */
+};
+
+template <int K>
+__device__ static inline void up_load_obs_reg(const UpArgs &a, int node, long sg, double (&out)[K])
+{
+    if (a.pat_mode == 1) {
+        const int ch = a.codes[(size_t)node * a.Spad + sg];
+        const double *dv = a.defs + (size_t)ch * K;
+#pragma unroll
+        for (int i = 0; i < K; i++) out[i] = dv[i];
+    } else {
+        const double *bp = a.B + (size_t)node * a.k * a.S + sg;
+#pragma unroll
+        for (int i = 0; i < K; i++) out[i] = i < a.k ? bp[(size_t)i * a.S] : 0.0;
+    }
+}
+
+template <int K>
+__device__ static inline void up_stage_obs(const UpArgs &a, int node, long sg, int tid, double (*xs)[GEN_BLOCK])
+{
+    if (a.pat_mode == 1) {
+        const int ch = a.codes[(size_t)node * a.Spad + sg];
+        const double *dv = a.defs + (size_t)ch * K;
+        for (int j = 0; j < a.k; j++) xs[j][tid] = dv[j];
+    } else {
+        const double *bp = a.B + (size_t)node * a.k * a.S + sg;
+        for (int j = 0; j < a.k; j++) xs[j][tid] = bp[(size_t)j * a.S];
+    }
+}
+
+/* acc[i] = sum_j M[j*K+i] * xs[j]  (M uniform, zero padded).
+ * CONST_MODE mirrors the reference's exact shortcut for a constant input column
+ * (src/util.c:276-283, :338-345; src/arb_mat_extras.c:36-51): a stochastic matrix maps
+ * it to itself (1), a rate matrix with zero row sums maps it to zero (2). */
+template <int K, int CONST_MODE>
+__device__ static inline void up_matvec(const double *M, int k, double (*xs)[GEN_BLOCK], int tid, double (&acc)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) acc[i] = 0.0;
+    const double x0 = xs[0][tid];
+    bool is_const = true;
+    for (int j = 0; j < k; j++) {
+        const double x = xs[j][tid];
+        is_const = is_const && (x == x0);
+        const double *col = M + j * K;
+#pragma unroll
+        for (int i = 0; i < K; i++) acc[i] = fma(col[i], x, acc[i]);
+    }
+    if (CONST_MODE != 0 && is_const) {
+#pragma unroll
+        for (int i = 0; i < K; i++) acc[i] = (CONST_MODE == 1 && i < k) ? x0 : 0.0;
+    }
+}
+
+/* down pass storing every edge vector and internal node vector (no rescaling) */
+template <int K>
+__global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
+{
+    __shared__ double xs[K][GEN_BLOCK];
+    const int tid = threadIdx.x;
+    const long sl = (long)blockIdx.x * GEN_BLOCK + tid;   /* local site */
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const size_t n = (size_t)a.n;
+    double lh_total = 0.0;
+    for (int c = 0; c < a.C; c++) {
+        double lh_c = 0.0;
+        for (int u = a.N - 1; u >= 0; u--) {
+            const int nd = a.preorder[u];
+            const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+            if (start == stop) continue;
+            double acc[K];
+            if (a.node_has_data[nd]) up_load_obs_reg<K>(a, nd, sg, acc);
+            else {
+#pragma unroll
+                for (int i = 0; i < K; i++) acc[i] = 1.0;
+            }
+            for (int idx = start; idx < stop; idx++) {
+                const int b = a.indices[idx];
+                if (a.indptr[b] == a.indptr[b + 1]) up_stage_obs<K>(a, b, sg, tid, xs);
+                else {
+                    const double *lb = a.LN + ((size_t)b * a.C + c) * a.k * n + slc;
+                    for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
+                }
+                double m[K];
+                up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, m);
+                double *ev = a.EV + ((size_t)idx * a.C + c) * a.k * n + slc;
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    if (i < a.k && valid) ev[(size_t)i * n] = m[i];
+                    acc[i] *= m[i];
+                }
+            }
+            double *ln = a.LN + ((size_t)nd * a.C + c) * a.k * n + slc;
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (i < a.k && valid) ln[(size_t)i * n] = acc[i];
+            if (u == 0) {
+                if (a.root_mode == PLK_ROOT_NONE || a.root_mode == PLK_ROOT_UNIFORM) {
+#pragma unroll
+                    for (int i = 0; i < K; i++)
+                        if (i < a.k) lh_c += acc[i];
+                    if (a.root_mode == PLK_ROOT_UNIFORM) lh_c /= (double)a.k;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) lh_c = fma(a.root_w[i], acc[i], lh_c);
+                }
+            }
+        }
+        lh_total = fma(a.cat_prior[c], lh_c, lh_total);
+    }
+    if (valid) a.LH[sl] = lh_total;
+}
+
+/*
+ * up pass in BFS order.  For every edge e = (a -> b):
+ *   fe   = F_a o B_a o prod_{siblings j != e} Ev_j          (src/evaluate_site_forward.c:69-94)
+ *   d_e  = sum_c prior_c * fe . (dP_{c,e} L_b) / lhood       (dP = r_c Q P; equals the reference's
+ *          rate * rootward recomputation with Q Ev_e, src/arbplfderiv.c:112-207, :312-342)
+ *   F_b  = P_e^T fe                                          (src/evaluate_site_forward.c:97-100)
+ *   m_b  = sum_c prior_c * F_b o L_b / lhood                 (src/arbplfmarginal.c:206-234)
+ */
+template <int K, bool DERIV, bool MARG>
+__global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
+{
+    __shared__ double xs[K][GEN_BLOCK];
+    const int tid = threadIdx.x;
+    const long sl = (long)blockIdx.x * GEN_BLOCK + tid;
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const size_t n = (size_t)a.n;
+    const double inv = 1.0 / a.LH[slc];
+    const int root = a.preorder[0];
+
+    /* root: forward vector = root prior weights; its marginal */
+    {
+        double macc[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) macc[i] = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            double *fr = a.FN + ((size_t)root * a.C + c) * a.k * n + slc;
+            const double *lr = a.LN + ((size_t)root * a.C + c) * a.k * n + slc;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                if (i < a.k) {
+                    if (valid) fr[(size_t)i * n] = a.root_w[i];
+                    if (MARG) macc[i] = fma(a.cat_prior[c] * a.root_w[i], lr[(size_t)i * n], macc[i]);
+                }
+            }
+        }
+        if (MARG && (!a.node_mask || a.node_mask[root])) {
+            double *mv = a.MV + (size_t)root * a.k * n + slc;
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (i < a.k && valid) mv[(size_t)i * n] = macc[i] * inv;
+        }
+    }
+
+    for (int u = 0; u < a.N; u++) {
+        const int nd = a.preorder[u];
+        const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+        if (start == stop) continue;
+        double bnd[K];
+        const bool has = a.node_has_data[nd];
+        if (has) up_load_obs_reg<K>(a, nd, sg, bnd);
+        for (int idx = start; idx < stop; idx++) {
+            const int b = a.indices[idx];
+            const bool b_leaf = a.indptr[b] == a.indptr[b + 1];
+            const bool want_d = DERIV && (!a.edge_mask || a.edge_mask[idx]);
+            const bool want_m = MARG && (!a.node_mask || a.node_mask[b]);
+            const bool want_f = !b_leaf || want_m;
+            if (!want_d && !want_f) continue;
+            double dsum = 0.0;
+            double macc[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) macc[i] = 0.0;
+            for (int c = 0; c < a.C; c++) {
+                double fe[K];
+                const double *fa = a.FN + ((size_t)nd * a.C + c) * a.k * n + slc;
+#pragma unroll
+                for (int i = 0; i < K; i++) fe[i] = i < a.k ? fa[(size_t)i * n] : 0.0;
+                if (has) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] *= bnd[i];
+                }
+                for (int idx2 = start; idx2 < stop; idx2++) {
+                    if (idx2 == idx) continue;
+                    const double *ev = a.EV + ((size_t)idx2 * a.C + c) * a.k * n + slc;
+#pragma unroll
+                    for (int i = 0; i < K; i++)
+                        if (i < a.k) fe[i] *= ev[(size_t)i * n];
+                }
+                const double prior = a.cat_prior[c];
+                if (want_d) {
+                    /* y = dP_e * L_b ; d = fe . y */
+                    if (b_leaf) up_stage_obs<K>(a, b, sg, tid, xs);
+                    else {
+                        const double *lb = a.LN + ((size_t)b * a.C + c) * a.k * n + slc;
+                        for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
+                    }
+                    double y[K];
+                    up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
+                    double d = 0.0;
+#pragma unroll
+                    for (int i = 0; i < K; i++) d = fma(fe[i], y[i], d);
+                    dsum = fma(prior, d, dsum);
+                }
+                if (want_f) {
+                    /* F_b[j] = sum_i P[i][j] fe[i]: stage fe, use the plain (row-major) P as the "transposed" operand */
+#pragma unroll
+                    for (int i = 0; i < K; i++) xs[i][tid] = fe[i];
+                    double fb[K];
+                    up_matvec<K, 0>(a.PN + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, fb);
+                    if (!b_leaf) {
+                        double *fo = a.FN + ((size_t)b * a.C + c) * a.k * n + slc;
+#pragma unroll
+                        for (int i = 0; i < K; i++)
+                            if (i < a.k && valid) fo[(size_t)i * n] = fb[i];
+                    }
+                    if (want_m) {
+                        if (b_leaf) {
+                            double lb[K];
+                            up_load_obs_reg<K>(a, b, sg, lb);
+#pragma unroll
+                            for (int i = 0; i < K; i++) macc[i] = fma(prior * fb[i], lb[i], macc[i]);
+                        } else {
+                            const double *lb = a.LN + ((size_t)b * a.C + c) * a.k * n + slc;
+#pragma unroll
+                            for (int i = 0; i < K; i++)
+                                if (i < a.k) macc[i] = fma(prior * fb[i], lb[(size_t)i * n], macc[i]);
+                        }
+                    }
+                }
+            }
+            if (want_d && valid) a.DV[(size_t)idx * n + sl] = dsum * inv;
+            if (want_m) {
+                double *mv = a.MV + (size_t)b * a.k * n + slc;
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if (i < a.k && valid) mv[(size_t)i * n] = macc[i] * inv;
+            }
+        }
+    }
+}
+
+/* padded edge-indexed matrix streams for the up/down kernels:
+ * mode 0: out[j*K+i] = M[i][j] (transposed), mode 1: out[i*K+j] = M[i][j] */
+__global__ void k_build_edge_stream(int k, int K, int mode, const double *__restrict__ M, double *__restrict__ out)
+{
+    const size_t ce = blockIdx.x;
+    const double *src = M + ce * k * k;
+    double *dst = out + ce * K * K;
+    for (int idx = threadIdx.x; idx < K * K; idx += blockDim.x) {
+        int r = idx / K, q = idx - r * K;
+        double v = 0.0;
+        if (r < k && q < k) v = mode == 0 ? src[q * k + r] : src[r * k + q];
+        dst[idx] = v;
+    }
+}
+
+/* ====================================================================== */
 /* host side                                                               */
 /* ====================================================================== */
 
@@ -778,7 +1064,8 @@ static int run_expm(plk_engine *h)
     return PLK_OK;
 }
 
-extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, const double *edge_rates_csr,
+extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, const double *Qn_lo,
+                             const double *edge_rates_csr,
                              const double *cat_rates, const double *cat_prior, int root_mode,
                              const double *root_w)
 {
@@ -793,6 +1080,8 @@ extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, cons
     if (h->k != k) { h->pat_mode = 0; }
     h->k = k; h->C = C; h->K = pad_K(k); h->root_mode = root_mode;
     h->Qn.assign(Qn, Qn + (size_t)k * k);
+    h->Qn.resize(2 * (size_t)k * k, 0.0);             /* [hi | lo] */
+    if (Qn_lo) std::copy(Qn_lo, Qn_lo + (size_t)k * k, h->Qn.begin() + (size_t)k * k);
     h->edge_rates.assign(edge_rates_csr, edge_rates_csr + h->E);
     h->cat_rates.assign(cat_rates, cat_rates + C);
     h->cat_prior.assign(cat_prior, cat_prior + C);
@@ -1148,18 +1437,145 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     return PLK_OK;
 }
 
+template <int K>
+static void launch_updown(plk_engine *h, const UpArgs &a, unsigned grid, bool deriv, bool marg)
+{
+    hipLaunchKernelGGL(k_down_store<K>, dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+    if (deriv && marg) hipLaunchKernelGGL((k_up<K, true, true>), dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+    else if (deriv) hipLaunchKernelGGL((k_up<K, true, false>), dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_up<K, false, true>), dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+}
+
+/* rows x n weighted sums of X (row stride n) accumulated into acc[rows] (long double pairs) */
+static int wsum_rows(plk_engine *h, int rows, long n, const double *X, const double *w, long double *acc)
+{
+    int rc;
+    const int nblocks = (int)std::min<long>(256, (n + 2047) / 2048);
+    if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)rows * nblocks + rows + 8))) return rc;
+    dd *outp = h->d_partial;
+    dd *part = h->d_partial + rows + 8;
+    hipLaunchKernelGGL(k_wsum_rows, dim3(nblocks, rows), dim3(256), 0, h->stream, n, n, X, w, nblocks, part);
+    hipLaunchKernelGGL(k_dd_final, dim3(rows), dim3(64), 0, h->stream, nblocks, part, outp);
+    HIPCHK(h, hipGetLastError());
+    std::vector<dd> host(rows);
+    HIPCHK(h, hipMemcpyAsync(host.data(), outp, rows * sizeof(dd), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < rows; r++) acc[r] += (long double)host[r].hi + (long double)host[r].lo;
+    return PLK_OK;
+}
+
+static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
+                      double *site_out, double *sums_out)
+{
+    if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_deriv/plk_marginal: tree, model and patterns must be set"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
+    const long S = h->S;
+    /* padded edge-indexed streams */
+    double *d_PT = nullptr, *d_PN = nullptr, *d_DT = nullptr;
+    int *d_emask = nullptr, *d_nmask = nullptr;
+    char *d_has = nullptr;
+    const size_t strm = (size_t)C * E * K * K;
+    auto cleanup = [&]() {
+        if (d_PT) (void)hipFree(d_PT);
+        if (d_PN) (void)hipFree(d_PN);
+        if (d_DT) (void)hipFree(d_DT);
+        if (d_emask) (void)hipFree(d_emask);
+        if (d_nmask) (void)hipFree(d_nmask);
+        if (d_has) (void)hipFree(d_has);
+    };
+    if ((rc = dev_alloc(h, &d_PT, strm)) || (rc = dev_alloc(h, &d_PN, strm)) || (rc = dev_alloc(h, &d_DT, strm))) { cleanup(); return rc; }
+    const int bt = K * K >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_P, d_PT);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 1, h->d_P, d_PN);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_dP, d_DT);
+    if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
+    if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
+    if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+    if ((rc = dev_upload(h, &d_has, h->node_has_data.data(), (size_t)N))) { cleanup(); return rc; }
+
+    /* chunk the site axis so that the stored vectors fit */
+    const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
+    budget += h->work_cap * sizeof(double);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
+    if (chunk < 1) { cleanup(); h->err = "plk_deriv/plk_marginal: not enough device memory for one site"; return PLK_E_NOMEM; }
+    if (chunk < S) chunk = std::max<long>(GEN_BLOCK, chunk / GEN_BLOCK * GEN_BLOCK);
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
+
+    std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
+    std::vector<double> stage;
+    for (long s0 = 0; s0 < S; s0 += chunk) {
+        const long n = std::min(chunk, S - s0);
+        UpArgs a;
+        a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
+        a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
+        a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
+        a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
+        a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
+        double *p = h->d_work;
+        a.EV = p; p += (size_t)E * C * k * n;
+        a.LN = p; p += (size_t)N * C * k * n;
+        a.FN = p; p += (size_t)N * C * k * n;
+        a.LH = p; p += n;
+        a.DV = p; if (deriv) p += (size_t)E * n;
+        a.MV = p; if (marg) p += (size_t)N * k * n;
+        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
+        const unsigned grid = (unsigned)((n + GEN_BLOCK - 1) / GEN_BLOCK);
+        switch (K) {
+        case 2: launch_updown<2>(h, a, grid, deriv, marg); break;
+        case 4: launch_updown<4>(h, a, grid, deriv, marg); break;
+        case 8: launch_updown<8>(h, a, grid, deriv, marg); break;
+        case 16: launch_updown<16>(h, a, grid, deriv, marg); break;
+        case 20: launch_updown<20>(h, a, grid, deriv, marg); break;
+        case 32: launch_updown<32>(h, a, grid, deriv, marg); break;
+        case 61: launch_updown<61>(h, a, grid, deriv, marg); break;
+        default: launch_updown<64>(h, a, grid, deriv, marg); break;
+        }
+        if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
+        if (sums_out) {
+            const double *w = h->d_w ? h->d_w + s0 : nullptr;
+            if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
+            if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
+        }
+        if (site_out) {
+            const size_t rows = deriv ? (size_t)E : (size_t)N * k;
+            stage.resize(rows * (size_t)n);
+            hipError_t e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+            for (size_t r = 0; r < rows; r++)
+                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
+        }
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) { h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+    if (sums_out) {
+        const std::vector<long double> &src = deriv ? dsum : msum;
+        for (size_t r = 0; r < src.size(); r++) {
+            const double hi = (double)src[r];
+            sums_out[2 * r] = hi;
+            sums_out[2 * r + 1] = (double)(src[r] - (long double)hi);
+        }
+    }
+    return PLK_OK;
+}
+
 extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_out, double *edge_sums_out)
 {
-    (void)edge_mask; (void)site_edge_out; (void)edge_sums_out;
     if (!h) return PLK_E_ARG;
-    h->err = "plk_deriv: not implemented yet";
-    return PLK_E_UNSUPPORTED;
+    return run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out);
 }
 
 extern "C" int plk_marginal(plk_engine *h, const int *node_mask, double *site_out, double *sums_out)
 {
-    (void)node_mask; (void)site_out; (void)sums_out;
     if (!h) return PLK_E_ARG;
-    h->err = "plk_marginal: not implemented yet";
-    return PLK_E_UNSUPPORTED;
+    return run_updown(h, false, true, nullptr, node_mask, site_out, sums_out);
 }

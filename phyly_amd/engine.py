@@ -45,7 +45,7 @@ def load_library():
     lib.plk_last_error.restype = ctypes.c_char_p
     lib.plk_create_error.restype = ctypes.c_char_p
     lib.plk_set_tree.argtypes = [vp, ci, vp, vp, vp]
-    lib.plk_set_model.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp]
+    lib.plk_set_model.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.plk_update_edge_rates.argtypes = [vp, vp]
     lib.plk_set_patterns_codes.argtypes = [vp, cl, vp, ci, ci, vp]
     lib.plk_set_patterns_dense.argtypes = [vp, cl, vp, ci]
@@ -112,14 +112,15 @@ class Engine:
         self.E = self.N - 1
         self._check(self._lib.plk_set_tree(self._h, self.N, _ptr(indptr), _ptr(indices), _ptr(preorder)))
 
-    def set_model(self, Qn, edge_rates_csr, cat_rates, cat_prior, root_mode, root_w=None):
+    def set_model(self, Qn, edge_rates_csr, cat_rates, cat_prior, root_mode, root_w=None, Qn_lo=None):
         Qn = _f64(Qn)
+        Qn_lo = _f64(Qn_lo) if Qn_lo is not None else None
         self.k = Qn.shape[0]
         cat_rates, cat_prior = _f64(cat_rates), _f64(cat_prior)
         self.C = len(cat_rates)
         er = _f64(edge_rates_csr)
         rw = _f64(root_w) if root_w is not None else None
-        self._check(self._lib.plk_set_model(self._h, self.k, self.C, _ptr(Qn), _ptr(er), _ptr(cat_rates),
+        self._check(self._lib.plk_set_model(self._h, self.k, self.C, _ptr(Qn), _ptr(Qn_lo), _ptr(er), _ptr(cat_rates),
                                             _ptr(cat_prior), int(root_mode), _ptr(rw)))
 
     def update_edge_rates(self, edge_rates_csr):

@@ -173,15 +173,16 @@ def k0_prepare(Q, mixture, use_eq_divisor=True, divisor=1.0, need_pi=True):
     prior = np.zeros(C)
     pi = np.zeros(k)
     Qn = np.zeros((k, k))
+    Qn_lo = np.zeros((k, k))
     dp = ctypes.POINTER(ctypes.c_double)
     lib.arbplf_k0_prepare.argtypes = [ctypes.c_int, dp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                      ctypes.POINTER(_K0Mixture), dp, dp, dp, dp]
+                                      ctypes.POINTER(_K0Mixture), dp, dp, dp, dp, dp]
     rc = lib.arbplf_k0_prepare(k, Q.ctypes.data_as(dp), int(use_eq_divisor), float(divisor), int(need_pi),
                                ctypes.byref(mix), rates.ctypes.data_as(dp), prior.ctypes.data_as(dp),
-                               pi.ctypes.data_as(dp), Qn.ctypes.data_as(dp))
+                               pi.ctypes.data_as(dp), Qn.ctypes.data_as(dp), Qn_lo.ctypes.data_as(dp))
     if rc != C:
         raise RuntimeError("arbplf_k0_prepare failed")
-    return dict(C=C, cat_rates=rates, cat_prior=prior, pi=pi, Qn=Qn)
+    return dict(C=C, cat_rates=rates, cat_prior=prior, pi=pi, Qn=Qn, Qn_lo=Qn_lo)
 
 
 # ---------------------------------------------------------------- simulation
@@ -340,7 +341,7 @@ class Workload:
         k0 = self.prepare()
         eng.set_tree(self.indptr, self.indices, self.preorder)
         eng.set_model(k0["Qn"], self.edge_rates_csr, k0["cat_rates"], k0["cat_prior"],
-                      _engine.ROOT_EQUILIBRIUM, k0["pi"])
+                      _engine.ROOT_EQUILIBRIUM, k0["pi"], Qn_lo=k0["Qn_lo"])
 
     def json_model(self, codes_host):
         """model_and_data dict for the JSON boundary (codes_host: [N][S] numpy)."""

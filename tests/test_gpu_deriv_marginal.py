@@ -1,0 +1,109 @@
+"""GPU parity of plk_deriv / plk_marginal (C-ABI) against the binary128 oracle on
+seeded synthetic workloads.
+
+Tolerance: |d| <= 1e-12 * max(|expected|, scale) where scale is the largest
+magnitude in the same site row."""
+import numpy as np
+import pytest
+
+from helpers import oracle_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from phyly_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _dense_from_codes(w, codes):
+    return w.defs[codes.T]          # [S][N][k]
+
+
+def _row_err(got, want):
+    got = got.reshape(got.shape[0], -1)
+    want = want.reshape(want.shape[0], -1)
+    scale = np.max(np.abs(want), axis=1, keepdims=True)
+    return np.max(np.abs(got - want) / np.maximum(np.abs(want), np.maximum(scale, 1e-300)))
+
+
+@pytest.mark.parametrize("cfg,S", [(2, 300), (3, 200), (4, 40), (5, 24)])
+def test_deriv_matches_oracle(eng, oracle, cfg, S):
+    from phyly_amd import synth
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    codes = w.simulate(S)
+    m, ow = oracle_model(oracle, w, codes)
+    want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes), precise=2 if w.k <= 4 else 1)
+    eng.set_patterns_codes(codes, w.defs)
+    wts = np.linspace(0.25, 1.75, S)
+    eng.set_site_weights(wts)
+    got, sums = eng.deriv()
+    assert _row_err(got, want) <= 1e-12
+    ref = (want.astype(np.longdouble) * wts[:, None].astype(np.longdouble)).sum(axis=0)
+    tot = sums[:, 0] + sums[:, 1]
+    assert np.max(np.abs(tot - ref.astype(float)) / np.max(np.abs(ref))) <= 1e-12
+
+
+def test_deriv_edge_mask_and_chunking(eng, oracle):
+    from phyly_amd import synth, engine as E
+    w = synth.Workload(3)
+    w.setup_engine(eng)
+    S = 500
+    codes = w.random_codes(S, seed=9)
+    m, ow = oracle_model(oracle, w, codes)
+    want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes), precise=2)
+    eng.set_patterns_codes(codes, w.defs)
+    mask = np.zeros(w.E, dtype=np.int32)
+    mask[::3] = 1
+    eng.set_option(E.OPT_SITE_CHUNK, 128)          # forces 4 chunks
+    got, sums = eng.deriv(edge_mask=mask)
+    eng.set_option(E.OPT_SITE_CHUNK, 0)
+    sel = mask.astype(bool)
+    assert _row_err(got[:, sel], want[:, sel]) <= 1e-12
+    assert np.all(got[:, ~sel] == 0.0)
+    ref = want.astype(np.longdouble).sum(axis=0).astype(float)
+    tot = sums[:, 0] + sums[:, 1]
+    assert np.max(np.abs(tot[sel] - ref[sel]) / np.max(np.abs(ref))) <= 1e-12
+
+
+@pytest.mark.parametrize("cfg,S", [(2, 300), (3, 200), (4, 40), (5, 24)])
+def test_marginal_matches_oracle(eng, oracle, cfg, S):
+    from phyly_amd import synth
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    codes = w.simulate(S)
+    m, ow = oracle_model(oracle, w, codes)
+    want = oracle.site_marginal(m, ow, _dense_from_codes(w, codes), precise=1)
+    eng.set_patterns_codes(codes, w.defs)
+    got, sums = eng.marginal()
+    assert np.max(np.abs(got - want)) <= 1e-12          # probabilities: absolute = relative to 1
+    np.testing.assert_allclose(got.sum(axis=2), 1.0, rtol=0, atol=1e-12)
+    tot = sums[..., 0] + sums[..., 1]
+    assert np.max(np.abs(tot - want.sum(axis=0))) <= 1e-12 * S
+
+
+def test_marginal_node_mask_dense(eng, oracle):
+    """dense observations with data on internal nodes; only some nodes requested"""
+    from phyly_amd import synth
+    w = synth.Workload(2)
+    w.setup_engine(eng)
+    S = 64
+    rng = np.random.default_rng(11)
+    B = rng.random((S, w.N, w.k)) + 0.05
+    B[:, 1::2, :] = 1.0
+    m, ow = oracle_model(oracle, w, w.simulate(1))
+    want = oracle.site_marginal(m, ow, B, precise=1)
+    wantd = oracle.site_deriv(m, ow, B, precise=2)
+    eng.set_patterns_dense(np.ascontiguousarray(B.transpose(1, 2, 0)))
+    mask = np.zeros(w.N, dtype=np.int32)
+    mask[[0, 5, w.N - 1, w.N // 2]] = 1
+    got, _ = eng.marginal(node_mask=mask)
+    sel = mask.astype(bool)
+    assert np.max(np.abs(got[:, sel] - want[:, sel])) <= 1e-12
+    assert np.all(got[:, ~sel] == 0.0)
+    gotd, _ = eng.deriv()
+    assert _row_err(gotd, wantd) <= 1e-12
