@@ -5,7 +5,7 @@ Harness code (bench.py / tests), not part of the likelihood path: it only
 builds inputs.  Trees, branch lengths, models and simulated site patterns
 follow SURVEY.md section 8(d).  The site simulator is a counter-based hash
 (splitmix64 of (seed, site, node)) evaluated with 64-bit integer arithmetic
-that is identical in numpy and in torch, so the CPU oracle and the GPU see
+that is identical in numpy and in torch, so the CPU checker and the GPU see
 the same sites for any site range without generating the whole alignment.
 """
 import ctypes
