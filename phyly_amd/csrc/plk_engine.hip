@@ -37,7 +37,7 @@
 
 #define PLK_MAX_K 64
 #define PLK_MAX_C 64
-#define PLK_FUSED_SLOTS 12
+#define PLK_FUSED_SLOTS 16
 #define PLK_TILE 256
 
 /* traversal program opcodes */
@@ -93,7 +93,10 @@ struct plk_engine {
     std::vector<int> obs_nodes;          /* nodes whose codes the fused kernel stages */
     int slots_needed = 0;
     int2 *d_ops = nullptr;
-    int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr;
+    int4 *d_fops = nullptr;              /* fused-kernel program */
+    std::vector<int> mat_edge;           /* CSR edge per compact matrix of the fused stream */
+    int first_row = 0;
+    int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr;
     double *d_PS = nullptr;              /* [C][nops][K*K] transposed: PS[j*K+i] = P[i][j] */
     double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
     size_t ps_cap = 0, tip_cap = 0;
@@ -363,15 +366,32 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 }
 
 /* ====================================================================== */
-/* K2+K3 fused: k = 4, register stack                                      */
+/* K2+K3 fused: k = 4, accumulation-register stack                         */
 /* ====================================================================== */
+
+/*
+ * One alignment site per lane.  The partial-likelihood vector being built lives in
+ * 4 VGPR pairs; vectors that must wait for a sibling subtree are parked in the
+ * AGPR half of the unified register file (gfx950: 512 registers per lane), so the
+ * traversal makes no HBM or LDS traffic for partials at all.  The program (ops)
+ * and the P matrices are wave-uniform and are fetched with scalar loads through
+ * the constant address space, one op ahead; FMAs take P entries as SGPR operands.
+ * Tip tables (P_e * definitions) of the current category and the tile's pattern
+ * codes sit in LDS.
+ */
+#define PLK_AS4 __attribute__((address_space(4)))
+template <typename T>
+__device__ static inline const PLK_AS4 T *as_uniform(const T *p)
+{
+    return (const PLK_AS4 T *)(p);
+}
 
 struct FusedArgs {
     long S, Spad;
-    int C, nops, ntips, nchar, nobs;
-    int root_mode;
-    const int2 *ops;
-    const double *PS;        /* [C][nops][16] transposed */
+    int C, nops, nmat, ntips, nchar, nobs;
+    int root_mode, first_row;
+    const int4 *ops;         /* x = opcode | tip<<8, y = row / slot, z = next observation row, w = matrix */
+    const double *PS;        /* [C][nmat][16] transposed: PS[j*4+i] = P[i][j] */
     const double *tip;       /* [C][ntips][nchar][4] */
     const uint8_t *codes;    /* [N][Spad] */
     const int *obs_nodes;    /* [nobs] node per staged row */
@@ -389,9 +409,59 @@ __device__ static inline int frexp_exp(double m)
     return m > 0.0 ? __builtin_amdgcn_frexp_exp(m) : 0;
 }
 
+template <int IDX>
+__device__ __forceinline__ void acc_write(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    asm volatile("v_accvgpr_write_b32 a[%2], %0\n\tv_accvgpr_write_b32 a[%3], %1"
+                 :: "v"(lo), "v"(hi), "n"(2 * IDX), "n"(2 * IDX + 1));
+}
+template <int IDX>
+__device__ __forceinline__ double acc_read()
+{
+    int lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
+                 : "=v"(lo), "=v"(hi) : "n"(2 * IDX), "n"(2 * IDX + 1));
+    return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ void stack_push(int d, double c0, double c1, double c2, double c3)
+{
+    if constexpr (D > 0) {
+        if (d == D - 1) {
+            acc_write<(D - 1) * 4 + 0>(c0); acc_write<(D - 1) * 4 + 1>(c1);
+            acc_write<(D - 1) * 4 + 2>(c2); acc_write<(D - 1) * 4 + 3>(c3);
+        } else stack_push<D - 1>(d, c0, c1, c2, c3);
+    }
+}
+template <int D>
+__device__ __forceinline__ void stack_popmul(int d, double &c0, double &c1, double &c2, double &c3)
+{
+    if constexpr (D > 0) {
+        if (d == D - 1) {
+            c0 *= acc_read<(D - 1) * 4 + 0>(); c1 *= acc_read<(D - 1) * 4 + 1>();
+            c2 *= acc_read<(D - 1) * 4 + 2>(); c3 *= acc_read<(D - 1) * 4 + 3>();
+        } else stack_popmul<D - 1>(d, c0, c1, c2, c3);
+    }
+}
+
+#define PLK_CLOBBER_A0_31 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
+#define PLK_CLOBBER_A32_63 "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+#define PLK_CLOBBER_A64_127 "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+
 template <int D>
 __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
 {
+    /* reserve the AGPRs the stack uses (8 per slot) */
+    if constexpr (D <= 4) asm volatile("" ::: PLK_CLOBBER_A0_31);
+    else if constexpr (D <= 8) asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
+    else asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);
+
     extern __shared__ double lds_dyn[];
     /* LDS: tip table of the current category, then the staged codes of this tile */
     double *tip_lds = lds_dyn;
@@ -414,6 +484,11 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
         }
     }
 
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(a.ops));
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior);
+    const PLK_AS4 double *rootw = as_uniform(a.root_w);
+    const int nchar4 = a.nchar * 4;
+
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
@@ -428,41 +503,37 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
         __syncthreads();
 
         double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;
-        double st[D][4];
-#pragma unroll
-        for (int d = 0; d < D; d++) { st[d][0] = st[d][1] = st[d][2] = st[d][3] = 0.0; }
         int esc = 0;
-        const double *PSc = a.PS + (size_t)c * a.nops * 16;
+        const PLK_AS4 double *PSc = as_uniform(a.PS) + (size_t)c * a.nmat * 16;
+        int ch_next = code_lds[a.first_row * PLK_TILE + tid];   /* code for the first observation op */
+        int op_x = ops[0], op_y = ops[1], op_z = ops[2], op_w = ops[3];
 
         for (int pc = 0; pc < a.nops; pc++) {
-            const int2 op = a.ops[pc];
-            const int code = op.x & 0xff;
+            /* one op ahead; the program is padded with one OP_END */
+            const int nop_x = ops[4 * pc + 4], nop_y = ops[4 * pc + 5], nop_z = ops[4 * pc + 6], nop_w = ops[4 * pc + 7];
+            const int code = op_x & 0xff;
             if (code == OP_MATVEC) {
-                const double *M = PSc + (size_t)pc * 16;
+                const PLK_AS4 double *M = PSc + op_w * 16;
                 double n0 = M[0] * c0, n1 = M[1] * c0, n2 = M[2] * c0, n3 = M[3] * c0;
                 n0 = fma(M[4], c1, n0); n1 = fma(M[5], c1, n1); n2 = fma(M[6], c1, n2); n3 = fma(M[7], c1, n3);
                 n0 = fma(M[8], c2, n0); n1 = fma(M[9], c2, n1); n2 = fma(M[10], c2, n2); n3 = fma(M[11], c2, n3);
                 n0 = fma(M[12], c3, n0); n1 = fma(M[13], c3, n1); n2 = fma(M[14], c3, n2); n3 = fma(M[15], c3, n3);
                 c0 = n0; c1 = n1; c2 = n2; c3 = n3;
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
-                const int t = op.x >> 8;
-                const int ch = code_lds[op.y * PLK_TILE + tid];
-                const double2 *tp = reinterpret_cast<const double2 *>(tip_lds + ((size_t)t * a.nchar + ch) * 4);
+                const int t = op_x >> 8;
+                const int ch = ch_next;
+                const double2 *tp = reinterpret_cast<const double2 *>(tip_lds + t * nchar4 + ch * 4);
                 const double2 v01 = tp[0], v23 = tp[1];
+                ch_next = code_lds[op_z * PLK_TILE + tid];
                 if (code == OP_TIP_SET) { c0 = v01.x; c1 = v01.y; c2 = v23.x; c3 = v23.y; }
                 else { c0 *= v01.x; c1 *= v01.y; c2 *= v23.x; c3 *= v23.y; }
             } else if (code == OP_PUSH) {
-                const int d = op.y;
-#pragma unroll
-                for (int i = 0; i < D; i++)
-                    if (d == i) { st[i][0] = c0; st[i][1] = c1; st[i][2] = c2; st[i][3] = c3; }
+                stack_push<D>(op_y, c0, c1, c2, c3);
             } else if (code == OP_POPMUL) {
-                const int d = op.y;
-#pragma unroll
-                for (int i = 0; i < D; i++)
-                    if (d == i) { c0 *= st[i][0]; c1 *= st[i][1]; c2 *= st[i][2]; c3 *= st[i][3]; }
+                stack_popmul<D>(op_y, c0, c1, c2, c3);
             } else if (code == OP_NODE_MUL) {
-                const int ch = code_lds[op.y * PLK_TILE + tid];
+                const int ch = ch_next;
+                ch_next = code_lds[op_z * PLK_TILE + tid];
                 const double *dv = a.defs + ch * 4;
                 c0 *= dv[0]; c1 *= dv[1]; c2 *= dv[2]; c3 *= dv[3];
             } else if (code == OP_SCALE) {
@@ -471,13 +542,14 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
                 c0 = ldexp(c0, -e); c1 = ldexp(c1, -e); c2 = ldexp(c2, -e); c3 = ldexp(c3, -e);
                 esc += e;
             }
+            op_x = nop_x; op_y = nop_y; op_z = nop_z; op_w = nop_w;
         }
         /* root expectation (src/model.c:283-350) and category mixing (src/arbplfll.c:165) */
         double lh;
         if (a.root_mode == PLK_ROOT_NONE) lh = ((c0 + c1) + c2) + c3;
         else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((c0 + c1) + c2) + c3) * 0.25;
-        else lh = fma(a.root_w[3], c3, fma(a.root_w[2], c2, fma(a.root_w[1], c1, a.root_w[0] * c0)));
-        const double term = a.cat_prior[c] * lh;
+        else lh = fma(rootw[3], c3, fma(rootw[2], c2, fma(rootw[1], c1, rootw[0] * c0)));
+        const double term = prior[c] * lh;
         if (term != 0.0) {
             if (!have) { sum = term; Eexp = esc; have = true; }
             else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
@@ -964,7 +1036,7 @@ extern "C" void plk_destroy(plk_engine *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
-                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
+                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
                     h->d_PS, h->d_tip, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1311,31 +1383,51 @@ static int prepare_stream(plk_engine *h, bool fused)
     int rc;
     const int nops = (int)h->ops.size();
     const int K = h->K, C = h->C;
-    if (!h->d_ops || h->stream_dirty) {
-        /* fused kernel addresses staged code rows, generic addresses nodes */
-        std::vector<int2> ops = h->ops;
-        if (fused) {
+    if (fused) {
+        if (!h->d_fops || h->stream_dirty) {
+            /* fused format: int4 {opcode|tip<<8, row/slot, next observation row, matrix index},
+             * compact matrix list, one trailing OP_END for the one-op-ahead fetch */
             std::vector<int> row(h->N, -1);
             for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-            for (auto &o : ops) {
-                int code = o.x & 0xff;
-                if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) o.y = row[o.y];
+            std::vector<int4> fops(nops + 1);
+            h->mat_edge.clear();
+            int next_row = 0;
+            for (int pc = nops - 1; pc >= 0; pc--) {
+                const int2 o = h->ops[pc];
+                const int code = o.x & 0xff;
+                int4 f; f.x = o.x; f.y = o.y; f.z = next_row; f.w = 0;
+                if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) { f.y = row[o.y]; next_row = f.y; }
+                fops[pc] = f;
             }
+            h->first_row = next_row;
+            for (int pc = 0; pc < nops; pc++)
+                if ((fops[pc].x & 0xff) == OP_MATVEC) { fops[pc].w = (int)h->mat_edge.size(); h->mat_edge.push_back(h->op_edge[pc]); }
+            int4 endop; endop.x = OP_END; endop.y = endop.z = endop.w = 0;
+            fops[nops] = endop;
+            if (h->mat_edge.empty()) h->mat_edge.push_back(0);
+            if ((rc = dev_upload(h, &h->d_fops, fops.data(), fops.size()))) return rc;
+            if ((rc = dev_upload(h, &h->d_mat_edge, h->mat_edge.data(), h->mat_edge.size()))) return rc;
+            if ((rc = dev_upload(h, &h->d_tip_edge, h->tip_edge.data(), h->tip_edge.size()))) return rc;
+            if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
         }
-        if ((rc = dev_upload(h, &h->d_ops, ops.data(), ops.size()))) return rc;
-        if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
-        if ((rc = dev_upload(h, &h->d_tip_edge, h->tip_edge.data(), h->tip_edge.size()))) return rc;
-        if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
-    }
-    if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;
-    hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
-                       h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
-    HIPCHK(h, hipGetLastError());
-    if (fused) {
+        const int nmat = (int)h->mat_edge.size();
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nmat * 16 + 16))) return rc;
+        hipLaunchKernelGGL(k_build_stream, dim3(nmat, C), dim3(64), 0, h->stream,
+                           h->k, K, h->E, nmat, h->d_mat_edge, h->d_P, h->d_PS);
+        HIPCHK(h, hipGetLastError());
         const int ntips = (int)h->tip_edge.size();
         if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)C * ntips * h->nchar * 4))) return rc;
         hipLaunchKernelGGL(k_build_tip, dim3(ntips, C), dim3(64), 0, h->stream,
                            h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        if (!h->d_ops || h->stream_dirty) {
+            if ((rc = dev_upload(h, &h->d_ops, h->ops.data(), h->ops.size()))) return rc;
+            if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
+        }
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;
+        hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
+                           h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
         HIPCHK(h, hipGetLastError());
     }
     h->stream_dirty = false;
@@ -1380,16 +1472,16 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         grid = (unsigned)((S + PLK_TILE - 1) / PLK_TILE);
         if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
         FusedArgs a;
-        a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size();
+        a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size(); a.nmat = (int)h->mat_edge.size();
         a.ntips = (int)h->tip_edge.size(); a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
-        a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS; a.tip = h->d_tip;
+        a.root_mode = h->root_mode; a.first_row = h->first_row; a.ops = h->d_fops; a.PS = h->d_PS; a.tip = h->d_tip;
         a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
         a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
         const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE;
         if (h->slots_needed <= 4) launch_fused<4>(h, a, grid, lds);
         else if (h->slots_needed <= 8) launch_fused<8>(h, a, grid, lds);
-        else launch_fused<PLK_FUSED_SLOTS>(h, a, grid, lds);
+        else launch_fused<16>(h, a, grid, lds);
         h->info_ll_kernel = 1;
     } else {
         grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);
