@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (2..5)")
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the config's S)")
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
+    ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -89,6 +90,8 @@ def main():
     wl.setup_engine(eng)
     if args.kernel == "generic":
         eng.set_option(E.OPT_FORCE_GENERIC, 1)
+    if args.fused_ns:
+        eng.set_option(E.OPT_FUSED_NS, args.fused_ns)
 
     # resident patterns: this rank's block of the alignment, generated on the GPU
     chunk = 1 << 20

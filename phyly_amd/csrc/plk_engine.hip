@@ -108,7 +108,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0;
 };
 
@@ -424,24 +424,35 @@ __device__ __forceinline__ double acc_read()
                  : "=v"(lo), "=v"(hi) : "n"(2 * IDX), "n"(2 * IDX + 1));
     return __hiloint2double(hi, lo);
 }
-template <int D>
-__device__ __forceinline__ void stack_push(int d, double c0, double c1, double c2, double c3)
+/* slot d of site j (compile-time j) lives in AGPR doubles ((d*NS + j)*4 .. +3) */
+template <int D, int NS>
+__device__ __forceinline__ void stack_push(int d, int j, double c0, double c1, double c2, double c3)
 {
     if constexpr (D > 0) {
         if (d == D - 1) {
-            acc_write<(D - 1) * 4 + 0>(c0); acc_write<(D - 1) * 4 + 1>(c1);
-            acc_write<(D - 1) * 4 + 2>(c2); acc_write<(D - 1) * 4 + 3>(c3);
-        } else stack_push<D - 1>(d, c0, c1, c2, c3);
+            if (j == 0) {
+                acc_write<((D - 1) * NS) * 4 + 0>(c0); acc_write<((D - 1) * NS) * 4 + 1>(c1);
+                acc_write<((D - 1) * NS) * 4 + 2>(c2); acc_write<((D - 1) * NS) * 4 + 3>(c3);
+            } else {
+                acc_write<((D - 1) * NS + (NS - 1)) * 4 + 0>(c0); acc_write<((D - 1) * NS + (NS - 1)) * 4 + 1>(c1);
+                acc_write<((D - 1) * NS + (NS - 1)) * 4 + 2>(c2); acc_write<((D - 1) * NS + (NS - 1)) * 4 + 3>(c3);
+            }
+        } else stack_push<D - 1, NS>(d, j, c0, c1, c2, c3);
     }
 }
-template <int D>
-__device__ __forceinline__ void stack_popmul(int d, double &c0, double &c1, double &c2, double &c3)
+template <int D, int NS>
+__device__ __forceinline__ void stack_popmul(int d, int j, double &c0, double &c1, double &c2, double &c3)
 {
     if constexpr (D > 0) {
         if (d == D - 1) {
-            c0 *= acc_read<(D - 1) * 4 + 0>(); c1 *= acc_read<(D - 1) * 4 + 1>();
-            c2 *= acc_read<(D - 1) * 4 + 2>(); c3 *= acc_read<(D - 1) * 4 + 3>();
-        } else stack_popmul<D - 1>(d, c0, c1, c2, c3);
+            if (j == 0) {
+                c0 *= acc_read<((D - 1) * NS) * 4 + 0>(); c1 *= acc_read<((D - 1) * NS) * 4 + 1>();
+                c2 *= acc_read<((D - 1) * NS) * 4 + 2>(); c3 *= acc_read<((D - 1) * NS) * 4 + 3>();
+            } else {
+                c0 *= acc_read<((D - 1) * NS + (NS - 1)) * 4 + 0>(); c1 *= acc_read<((D - 1) * NS + (NS - 1)) * 4 + 1>();
+                c2 *= acc_read<((D - 1) * NS + (NS - 1)) * 4 + 2>(); c3 *= acc_read<((D - 1) * NS + (NS - 1)) * 4 + 3>();
+            }
+        } else stack_popmul<D - 1, NS>(d, j, c0, c1, c2, c3);
     }
 }
 
@@ -454,12 +465,74 @@ __device__ __forceinline__ void stack_popmul(int d, double &c0, double &c1, doub
     "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
     "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 
-template <int D>
+/* one traversal op: OUT = f(IN) for the NS sites of this lane (IN and OUT are distinct
+ * register sets; the caller alternates them so that no result has to be copied back) */
+#define PLK_FUSED_EXEC(OX, OY, OZ, IN, OUT)                                                              \
+    do {                                                                                                  \
+        const int code_ = (OX) & 0xff;                                                                    \
+        if (code_ == OP_MATVEC) {                                                                         \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                double n0 = m0 * IN[j][0], n1 = m1 * IN[j][0], n2 = m2 * IN[j][0], n3 = m3 * IN[j][0];    \
+                n0 = fma(m4, IN[j][1], n0); n1 = fma(m5, IN[j][1], n1); n2 = fma(m6, IN[j][1], n2); n3 = fma(m7, IN[j][1], n3);     \
+                n0 = fma(m8, IN[j][2], n0); n1 = fma(m9, IN[j][2], n1); n2 = fma(m10, IN[j][2], n2); n3 = fma(m11, IN[j][2], n3);   \
+                n0 = fma(m12, IN[j][3], n0); n1 = fma(m13, IN[j][3], n1); n2 = fma(m14, IN[j][3], n2); n3 = fma(m15, IN[j][3], n3); \
+                OUT[j][0] = n0; OUT[j][1] = n1; OUT[j][2] = n2; OUT[j][3] = n3;                           \
+            }                                                                                             \
+            mi++;                                                                                         \
+            PLK_LOAD_M(PSc + mi * 16);   /* matrices are consumed in stream order */                      \
+        } else if (code_ == OP_TIP_MUL || code_ == OP_TIP_SET) {                                          \
+            const int t_ = (OX) >> 8;                                                                     \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                const double2 *tp = reinterpret_cast<const double2 *>(tip_lds + t_ * nchar4 + ch_next[j] * 4); \
+                const double2 v01 = tp[0], v23 = tp[1];                                                   \
+                ch_next[j] = code_lds[(OZ) * (PLK_TILE * NS) + j * PLK_TILE + tid];                       \
+                if (code_ == OP_TIP_SET) { OUT[j][0] = v01.x; OUT[j][1] = v01.y; OUT[j][2] = v23.x; OUT[j][3] = v23.y; } \
+                else { OUT[j][0] = IN[j][0] * v01.x; OUT[j][1] = IN[j][1] * v01.y; OUT[j][2] = IN[j][2] * v23.x; OUT[j][3] = IN[j][3] * v23.y; } \
+            }                                                                                             \
+        } else if (code_ == OP_POPMUL) {                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                OUT[j][0] = IN[j][0]; OUT[j][1] = IN[j][1]; OUT[j][2] = IN[j][2]; OUT[j][3] = IN[j][3];   \
+                stack_popmul<D, NS>((OY), j, OUT[j][0], OUT[j][1], OUT[j][2], OUT[j][3]);                 \
+            }                                                                                             \
+        } else if (code_ == OP_PUSH) {                                                                    \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                stack_push<D, NS>((OY), j, IN[j][0], IN[j][1], IN[j][2], IN[j][3]);                       \
+                OUT[j][0] = IN[j][0]; OUT[j][1] = IN[j][1]; OUT[j][2] = IN[j][2]; OUT[j][3] = IN[j][3];   \
+            }                                                                                             \
+        } else if (code_ == OP_SCALE) {                                                                   \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                const double mx = fmax(fmax(IN[j][0], IN[j][1]), fmax(IN[j][2], IN[j][3]));               \
+                const int e = frexp_exp(mx);                                                              \
+                OUT[j][0] = ldexp(IN[j][0], -e); OUT[j][1] = ldexp(IN[j][1], -e);                         \
+                OUT[j][2] = ldexp(IN[j][2], -e); OUT[j][3] = ldexp(IN[j][3], -e);                         \
+                esc[j] += e;                                                                              \
+            }                                                                                             \
+        } else if (code_ == OP_NODE_MUL) {                                                                \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                const double *dv = a.defs + ch_next[j] * 4;                                               \
+                ch_next[j] = code_lds[(OZ) * (PLK_TILE * NS) + j * PLK_TILE + tid];                       \
+                OUT[j][0] = IN[j][0] * dv[0]; OUT[j][1] = IN[j][1] * dv[1];                               \
+                OUT[j][2] = IN[j][2] * dv[2]; OUT[j][3] = IN[j][3] * dv[3];                               \
+            }                                                                                             \
+        } else { /* OP_END / padding: pass through */                                                     \
+            _Pragma("unroll") for (int j = 0; j < NS; j++) {                                              \
+                OUT[j][0] = IN[j][0]; OUT[j][1] = IN[j][1]; OUT[j][2] = IN[j][2]; OUT[j][3] = IN[j][3];   \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+
+#define PLK_LOAD_M(P_)                                                                          \
+    do {                                                                                        \
+        m0 = (P_)[0]; m1 = (P_)[1]; m2 = (P_)[2]; m3 = (P_)[3]; m4 = (P_)[4]; m5 = (P_)[5]; m6 = (P_)[6]; m7 = (P_)[7]; \
+        m8 = (P_)[8]; m9 = (P_)[9]; m10 = (P_)[10]; m11 = (P_)[11]; m12 = (P_)[12]; m13 = (P_)[13]; m14 = (P_)[14]; m15 = (P_)[15]; \
+    } while (0)
+
+template <int D, int NS>
 __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
 {
-    /* reserve the AGPRs the stack uses (8 per slot) */
-    if constexpr (D <= 4) asm volatile("" ::: PLK_CLOBBER_A0_31);
-    else if constexpr (D <= 8) asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
+    /* reserve the AGPRs the stack uses (8 per slot and site) */
+    if constexpr (D * NS <= 4) asm volatile("" ::: PLK_CLOBBER_A0_31);
+    else if constexpr (D * NS <= 8) asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
     else asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);
 
     extern __shared__ double lds_dyn[];
@@ -467,18 +540,17 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
     double *tip_lds = lds_dyn;
     const int tip_doubles = a.ntips * a.nchar * 4;
     uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_dyn + tip_doubles);
+    constexpr int TILE = PLK_TILE * NS;
 
-    const long tile0 = (long)blockIdx.x * PLK_TILE;
+    const long tile0 = (long)blockIdx.x * TILE;
     const int tid = threadIdx.x;
-    const long s = tile0 + tid;
-    const bool valid = s < a.S;
 
-    /* stage codes[obs][256] for this tile: rows are padded to Spad (multiple of 256) */
+    /* stage codes[obs][TILE] for this tile: rows are padded to Spad (multiple of 1024) */
     {
-        const int ndw = a.nobs * (PLK_TILE / 4);
+        const int ndw = a.nobs * (TILE / 4);
         uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
         for (int idx = tid; idx < ndw; idx += PLK_TILE) {
-            int row = idx >> 6, col = idx & 63;
+            int row = idx / (TILE / 4), col = idx - row * (TILE / 4);
             const uint32_t *src = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad + tile0);
             dst[idx] = src[col];
         }
@@ -489,9 +561,11 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
     const PLK_AS4 double *rootw = as_uniform(a.root_w);
     const int nchar4 = a.nchar * 4;
 
-    double sum = 0.0;
-    int Eexp = 0;
-    bool have = false;
+    double sum[NS];
+    int Eexp[NS];
+    bool have[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) { sum[j] = 0.0; Eexp[j] = 0; have[j] = false; }
 
     for (int c = 0; c < a.C; c++) {
         __syncthreads();
@@ -502,69 +576,61 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4(FusedArgs a)
         }
         __syncthreads();
 
-        double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;
-        int esc = 0;
-        const PLK_AS4 double *PSc = as_uniform(a.PS) + (size_t)c * a.nmat * 16;
-        int ch_next = code_lds[a.first_row * PLK_TILE + tid];   /* code for the first observation op */
-        int op_x = ops[0], op_y = ops[1], op_z = ops[2], op_w = ops[3];
+        double A[NS][4], B[NS][4];
+        int esc[NS], ch_next[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            A[j][0] = A[j][1] = A[j][2] = A[j][3] = 1.0;
+            esc[j] = 0;
+            ch_next[j] = code_lds[a.first_row * TILE + j * PLK_TILE + tid];   /* code for the first observation op */
+        }
+        const PLK_AS4 double *PSc = as_uniform(a.PS) + (size_t)c * (a.nmat + 1) * 16;
+        int mi = 0;
+        double m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15;
+        PLK_LOAD_M(PSc);
+        int ax = ops[0], ay = ops[1], az = ops[2];
+        int bx = ops[4], by = ops[5], bz = ops[6];
 
-        for (int pc = 0; pc < a.nops; pc++) {
-            /* one op ahead; the program is padded with one OP_END */
-            const int nop_x = ops[4 * pc + 4], nop_y = ops[4 * pc + 5], nop_z = ops[4 * pc + 6], nop_w = ops[4 * pc + 7];
-            const int code = op_x & 0xff;
-            if (code == OP_MATVEC) {
-                const PLK_AS4 double *M = PSc + op_w * 16;
-                double n0 = M[0] * c0, n1 = M[1] * c0, n2 = M[2] * c0, n3 = M[3] * c0;
-                n0 = fma(M[4], c1, n0); n1 = fma(M[5], c1, n1); n2 = fma(M[6], c1, n2); n3 = fma(M[7], c1, n3);
-                n0 = fma(M[8], c2, n0); n1 = fma(M[9], c2, n1); n2 = fma(M[10], c2, n2); n3 = fma(M[11], c2, n3);
-                n0 = fma(M[12], c3, n0); n1 = fma(M[13], c3, n1); n2 = fma(M[14], c3, n2); n3 = fma(M[15], c3, n3);
-                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-            } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
-                const int t = op_x >> 8;
-                const int ch = ch_next;
-                const double2 *tp = reinterpret_cast<const double2 *>(tip_lds + t * nchar4 + ch * 4);
-                const double2 v01 = tp[0], v23 = tp[1];
-                ch_next = code_lds[op_z * PLK_TILE + tid];
-                if (code == OP_TIP_SET) { c0 = v01.x; c1 = v01.y; c2 = v23.x; c3 = v23.y; }
-                else { c0 *= v01.x; c1 *= v01.y; c2 *= v23.x; c3 *= v23.y; }
-            } else if (code == OP_PUSH) {
-                stack_push<D>(op_y, c0, c1, c2, c3);
-            } else if (code == OP_POPMUL) {
-                stack_popmul<D>(op_y, c0, c1, c2, c3);
-            } else if (code == OP_NODE_MUL) {
-                const int ch = ch_next;
-                ch_next = code_lds[op_z * PLK_TILE + tid];
-                const double *dv = a.defs + ch * 4;
-                c0 *= dv[0]; c1 *= dv[1]; c2 *= dv[2]; c3 *= dv[3];
-            } else if (code == OP_SCALE) {
-                const double m = fmax(fmax(c0, c1), fmax(c2, c3));
-                const int e = frexp_exp(m);
-                c0 = ldexp(c0, -e); c1 = ldexp(c1, -e); c2 = ldexp(c2, -e); c3 = ldexp(c3, -e);
-                esc += e;
-            }
-            op_x = nop_x; op_y = nop_y; op_z = nop_z; op_w = nop_w;
+        /* ops are executed in pairs (program padded to an even count + one spare pair) */
+        for (int pc = 0; pc < a.nops; pc += 2) {
+            const int nax = ops[4 * pc + 8], nay = ops[4 * pc + 9], naz = ops[4 * pc + 10];
+            const int nbx = ops[4 * pc + 12], nby = ops[4 * pc + 13], nbz = ops[4 * pc + 14];
+            PLK_FUSED_EXEC(ax, ay, az, A, B);
+            PLK_FUSED_EXEC(bx, by, bz, B, A);
+            ax = nax; ay = nay; az = naz; bx = nbx; by = nby; bz = nbz;
         }
         /* root expectation (src/model.c:283-350) and category mixing (src/arbplfll.c:165) */
-        double lh;
-        if (a.root_mode == PLK_ROOT_NONE) lh = ((c0 + c1) + c2) + c3;
-        else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((c0 + c1) + c2) + c3) * 0.25;
-        else lh = fma(rootw[3], c3, fma(rootw[2], c2, fma(rootw[1], c1, rootw[0] * c0)));
-        const double term = prior[c] * lh;
-        if (term != 0.0) {
-            if (!have) { sum = term; Eexp = esc; have = true; }
-            else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
-            else sum += ldexp(term, esc - Eexp);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            double lh;
+            if (a.root_mode == PLK_ROOT_NONE) lh = ((A[j][0] + A[j][1]) + A[j][2]) + A[j][3];
+            else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((A[j][0] + A[j][1]) + A[j][2]) + A[j][3]) * 0.25;
+            else lh = fma(rootw[3], A[j][3], fma(rootw[2], A[j][2], fma(rootw[1], A[j][1], rootw[0] * A[j][0])));
+            const double term = prior[c] * lh;
+            if (term != 0.0) {
+                if (!have[j]) { sum[j] = term; Eexp[j] = esc[j]; have[j] = true; }
+                else if (esc[j] > Eexp[j]) { sum[j] = ldexp(sum[j], Eexp[j] - esc[j]) + term; Eexp[j] = esc[j]; }
+                else sum[j] += ldexp(term, esc[j] - Eexp[j]);
+            }
         }
     }
-    const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
-    if (valid && a.site_ll) a.site_ll[s] = ll;
+    dd v = dd_make(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const long s = tile0 + j * PLK_TILE + tid;
+        const double ll = have[j] ? log(sum[j]) + (double)Eexp[j] * 0.6931471805599453094 : -INFINITY;
+        if (s < a.S) {
+            if (a.site_ll) a.site_ll[s] = ll;
+            v = dd_add(v, a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0));
+        }
+    }
     if (a.partial) {
-        dd v = dd_make(0.0, 0.0);
-        if (valid) v = a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0);
         dd r = dd_block_sum(v);
         if (tid == 0) a.partial[blockIdx.x] = r;
     }
 }
+#undef PLK_LOAD_M
+#undef PLK_FUSED_EXEC
 
 /* ====================================================================== */
 /* K2+K3 generic: any k <= K, stack slots in HBM                           */
@@ -1054,6 +1120,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (!h) return PLK_E_ARG;
     if (option == PLK_OPT_FORCE_GENERIC) { h->opt_force_generic = value; h->prog_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
+    if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1212,7 +1279,7 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
     if (S < 1 || !codes || nchar < 1 || nchar > 256 || !defs) { h->err = "plk_set_patterns_codes: bad arguments"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     const int k = h->k, K = h->K, N = h->N;
-    const long Spad = (S + PLK_TILE - 1) / PLK_TILE * PLK_TILE;
+    const long Spad = (S + 1023) / 1024 * 1024;
     int rc;
     if ((rc = dev_alloc(h, &h->d_codes, (size_t)N * Spad))) return rc;
     HIPCHK(h, hipMemset(h->d_codes, 0, (size_t)N * Spad));
@@ -1368,13 +1435,24 @@ static int build_program(plk_engine *h)
     return PLK_OK;
 }
 
+/* sites per lane of the fused kernel: 2 when the AGPR stack (<= 8 slots) and LDS allow it */
+static int fused_sites_per_lane(const plk_engine *h)
+{
+    if (h->opt_fused_ns == 1 || h->opt_fused_ns == 2) {
+        if (h->opt_fused_ns == 2 && h->slots_needed > 8) return 1;
+        return (int)h->opt_fused_ns;
+    }
+    const size_t lds2 = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE * 2;
+    return (h->slots_needed <= 8 && lds2 <= 80 * 1024) ? 2 : 1;
+}
+
 static bool use_fused(const plk_engine *h)
 {
     if (h->opt_force_generic) return false;
     if (h->k != 4 || h->pat_mode != 1) return false;
     if (h->slots_needed > PLK_FUSED_SLOTS) return false;
     const size_t lds = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE;
-    return lds <= 60 * 1024;
+    return lds <= 150 * 1024;
 }
 
 /* upload the program and (re)build the matrix stream / tip tables */
@@ -1389,7 +1467,8 @@ static int prepare_stream(plk_engine *h, bool fused)
              * compact matrix list, one trailing OP_END for the one-op-ahead fetch */
             std::vector<int> row(h->N, -1);
             for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-            std::vector<int4> fops(nops + 1);
+            const int npad = ((nops + 1) / 2) * 2 + 2;   /* even count + one spare pair for the look-ahead */
+            std::vector<int4> fops(npad);
             h->mat_edge.clear();
             int next_row = 0;
             for (int pc = nops - 1; pc >= 0; pc--) {
@@ -1403,17 +1482,21 @@ static int prepare_stream(plk_engine *h, bool fused)
             for (int pc = 0; pc < nops; pc++)
                 if ((fops[pc].x & 0xff) == OP_MATVEC) { fops[pc].w = (int)h->mat_edge.size(); h->mat_edge.push_back(h->op_edge[pc]); }
             int4 endop; endop.x = OP_END; endop.y = endop.z = endop.w = 0;
-            fops[nops] = endop;
-            if (h->mat_edge.empty()) h->mat_edge.push_back(0);
+            for (int pc = nops; pc < npad; pc++) fops[pc] = endop;
             if ((rc = dev_upload(h, &h->d_fops, fops.data(), fops.size()))) return rc;
-            if ((rc = dev_upload(h, &h->d_mat_edge, h->mat_edge.data(), h->mat_edge.size()))) return rc;
+            {
+                std::vector<int> me = h->mat_edge;
+                me.push_back(-1);                        /* the spare matrix is all zeros */
+                if ((rc = dev_upload(h, &h->d_mat_edge, me.data(), me.size()))) return rc;
+            }
             if ((rc = dev_upload(h, &h->d_tip_edge, h->tip_edge.data(), h->tip_edge.size()))) return rc;
             if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
         }
         const int nmat = (int)h->mat_edge.size();
-        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nmat * 16 + 16))) return rc;
-        hipLaunchKernelGGL(k_build_stream, dim3(nmat, C), dim3(64), 0, h->stream,
-                           h->k, K, h->E, nmat, h->d_mat_edge, h->d_P, h->d_PS);
+        /* one spare matrix per category: the kernel always keeps the next matrix of the stream loaded */
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * (nmat + 1) * 16))) return rc;
+        hipLaunchKernelGGL(k_build_stream, dim3(nmat + 1, C), dim3(64), 0, h->stream,
+                           h->k, K, h->E, nmat + 1, h->d_mat_edge, h->d_P, h->d_PS);
         HIPCHK(h, hipGetLastError());
         const int ntips = (int)h->tip_edge.size();
         if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)C * ntips * h->nchar * 4))) return rc;
@@ -1434,10 +1517,10 @@ static int prepare_stream(plk_engine *h, bool fused)
     return PLK_OK;
 }
 
-template <int D>
+template <int D, int NS>
 static void launch_fused(plk_engine *h, const FusedArgs &a, unsigned grid, size_t lds)
 {
-    hipLaunchKernelGGL(k_ll_fused4<D>, dim3(grid), dim3(PLK_TILE), lds, h->stream, a);
+    hipLaunchKernelGGL((k_ll_fused4<D, NS>), dim3(grid), dim3(PLK_TILE), lds, h->stream, a);
 }
 
 template <int K>
@@ -1469,7 +1552,8 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     unsigned grid;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     if (fused) {
-        grid = (unsigned)((S + PLK_TILE - 1) / PLK_TILE);
+        const int NS = fused_sites_per_lane(h);
+        grid = (unsigned)((S + PLK_TILE * NS - 1) / (PLK_TILE * NS));
         if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
         FusedArgs a;
         a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size(); a.nmat = (int)h->mat_edge.size();
@@ -1478,10 +1562,15 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
         a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
-        const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE;
-        if (h->slots_needed <= 4) launch_fused<4>(h, a, grid, lds);
-        else if (h->slots_needed <= 8) launch_fused<8>(h, a, grid, lds);
-        else launch_fused<16>(h, a, grid, lds);
+        const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE * NS;
+        if (NS == 2) {
+            if (h->slots_needed <= 4) launch_fused<4, 2>(h, a, grid, lds);
+            else launch_fused<8, 2>(h, a, grid, lds);
+        } else {
+            if (h->slots_needed <= 4) launch_fused<4, 1>(h, a, grid, lds);
+            else if (h->slots_needed <= 8) launch_fused<8, 1>(h, a, grid, lds);
+            else launch_fused<16, 1>(h, a, grid, lds);
+        }
         h->info_ll_kernel = 1;
     } else {
         grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);

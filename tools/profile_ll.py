@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Minimal driver for rocprofv3 counter passes: runs the ll hot path on a BASELINE
+config with host-generated pattern codes and no torch kernels, so that PMC
+collection only sees the engine's own kernels.
+
+  rocprofv3 --kernel-trace --pmc ... --kernel-include-regex 'k_ll' -- python3 tools/profile_ll.py --config 3 --sites 2000000
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--sites", type=int, default=2_000_000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
+    ap.add_argument("--what", choices=["ll", "deriv", "marginal"], default="ll")
+    ap.add_argument("--fused-ns", type=int, default=0)
+    args = ap.parse_args()
+    from phyly_amd import synth, engine as E
+    wl = synth.Workload(args.config)
+    eng = E.Engine(0)
+    wl.setup_engine(eng)
+    if args.kernel == "generic":
+        eng.set_option(E.OPT_FORCE_GENERIC, 1)
+    if args.fused_ns:
+        eng.set_option(E.OPT_FUSED_NS, args.fused_ns)
+    # realistic codes for a block of sites, tiled to the requested size
+    base = wl.simulate(min(args.sites, 4096))
+    reps = -(-args.sites // base.shape[1])
+    codes = np.ascontiguousarray(np.tile(base, (1, reps))[:, :args.sites])
+    eng.set_patterns_codes(codes, wl.defs)
+    for i in range(args.steps):
+        eng.update_edge_rates(wl.edge_rates_csr)
+        t0 = time.perf_counter()
+        if args.what == "ll":
+            _, s = eng.ll(per_site=False)
+            extra = "kernel %.3f ms" % (eng.info(E.INFO_LL_KERNEL_NS) * 1e-6)
+        elif args.what == "deriv":
+            _, s = eng.deriv(per_site=False)
+            extra = ""
+        else:
+            _, s = eng.marginal(per_site=False)
+            extra = ""
+        dt = time.perf_counter() - t0
+        print("step %d: %.3f ms wall, %.1f Msites/s %s" % (i, dt * 1e3, args.sites / dt / 1e6, extra), flush=True)
+
+
+if __name__ == "__main__":
+    main()
