@@ -146,7 +146,8 @@ enum {
 /* force the generic (HBM-resident partials) traversal even where the fused
  * kernel applies; used by tests and by bench.py --kernel generic */
 int plk_set_option(plk_engine *h, int option, long value);
-enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PER_LANE = 2 /* 0 auto, 1, 2 */ };
+enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PER_LANE = 2 /* 0 auto, 1, 2 */,
+       PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */ };
 
 #ifdef __cplusplus
 }

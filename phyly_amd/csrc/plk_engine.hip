@@ -108,7 +108,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0;
 };
 
@@ -366,6 +366,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 }
 
 #include "plk_fused4.h"
+#include "plk_fused4_asm.h"
 
 /* ====================================================================== */
 /* K2+K3 generic: any k <= K, stack slots in HBM                           */
@@ -856,6 +857,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_FORCE_GENERIC) { h->opt_force_generic = value; h->prog_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
     if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; return PLK_OK; }
+    if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1178,7 +1180,8 @@ static int fused_sites_per_lane(const plk_engine *h)
         return (int)h->opt_fused_ns;
     }
     const size_t lds2 = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE * 2;
-    return (h->slots_needed <= 8 && lds2 <= 80 * 1024) ? 2 : 1;
+    (void)lds2;
+    return 1;   /* the assembly interpreter (one site per lane) is the fastest variant measured */
 }
 
 static bool use_fused(const plk_engine *h)
@@ -1298,7 +1301,9 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
         a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
         const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE * NS;
-        if (NS == 2) {
+        if (NS == 1 && h->slots_needed <= 8 && h->opt_fused_asm) {
+            hipLaunchKernelGGL(k_ll_fused4_asm, dim3(grid), dim3(PLK_TILE), lds, h->stream, a);
+        } else if (NS == 2) {
             if (h->slots_needed <= 4) launch_fused<4, 2>(h, a, grid, lds);
             else launch_fused<8, 2>(h, a, grid, lds);
         } else {
