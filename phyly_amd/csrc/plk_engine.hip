@@ -93,7 +93,10 @@ struct plk_engine {
     std::vector<int> obs_nodes;          /* nodes whose codes the fused kernel stages */
     int slots_needed = 0;
     int2 *d_ops = nullptr;
-    int4 *d_fops = nullptr;              /* fused-kernel program */
+    int4 *d_fops = nullptr;              /* fused-kernel program (C++ interpreter) */
+    unsigned *d_words = nullptr;         /* fused-kernel program (assembly interpreter) */
+    bool asm_ok = false;
+    int asm_first_tip = 0, asm_first_row = 0, asm_second_row = 0;
     std::vector<int> mat_edge;           /* CSR edge per compact matrix of the fused stream */
     int first_row = 0;
     int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr;
@@ -278,12 +281,14 @@ __global__ void k_build_tip(int E, int ntips, int nchar, const int *__restrict__
 {
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
-    const dd *Pm = Pdd + ((size_t)c * E + e) * 16;
+    const dd *Pm = Pdd + ((size_t)c * E + (e < 0 ? 0 : e)) * 16;
     for (int idx = threadIdx.x; idx < nchar * 4; idx += blockDim.x) {
         int code = idx >> 2, i = idx & 3;
         const double *d = defs + code * 4;
         double out;
-        if (d[0] == d[1] && d[0] == d[2] && d[0] == d[3]) {
+        if (e < 0) {
+            out = d[i];                          /* pseudo slot: the definition itself */
+        } else if (d[0] == d[1] && d[0] == d[2] && d[0] == d[3]) {
             out = d[0];
         } else {
             dd acc = dd_make(0.0, 0.0);
@@ -298,10 +303,22 @@ __global__ void k_build_tip(int E, int ntips, int nchar, const int *__restrict__
 __global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes,
                              const int *__restrict__ code_trivial, int *__restrict__ flags)
 {
+    /* 16 codes per lane and iteration (rows are 1024-byte padded with code 0 beyond S;
+     * the tail is masked), grid-stride over the row */
     const int n = blockIdx.y;
-    long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *row = reinterpret_cast<const uint4 *>(codes + (size_t)n * Spad);
+    const long nvec = (S + 15) / 16;
     int bad = 0;
-    if (s < S) bad = !code_trivial[codes[(size_t)n * Spad + s]];
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const uint4 q = row[v];
+        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const long s = v * 16 + j;
+            const int ch = (wds[j >> 2] >> ((j & 3) * 8)) & 0xff;
+            if (s < S) bad |= !code_trivial[ch];
+        }
+    }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[n], 1);
 }
 
@@ -838,7 +855,7 @@ extern "C" void plk_destroy(plk_engine *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
-                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
+                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
                     h->d_PS, h->d_tip, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1039,7 +1056,7 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
     if ((rc = dev_upload(h, &d_triv, trivial.data(), trivial.size()))) return rc;
     if ((rc = dev_alloc(h, &d_flags, (size_t)N))) { (void)hipFree(d_triv); return rc; }
     HIPCHK(h, hipMemset(d_flags, 0, N * sizeof(int)));
-    hipLaunchKernelGGL(k_node_flags, dim3((unsigned)((S + 255) / 256), N), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(k_node_flags, dim3((unsigned)std::min<long>(64, (S + 4095) / 4096), N), dim3(256), 0, h->stream,
                        S, Spad, h->d_codes, d_triv, d_flags);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1189,7 +1206,7 @@ static bool use_fused(const plk_engine *h)
     if (h->opt_force_generic) return false;
     if (h->k != 4 || h->pat_mode != 1) return false;
     if (h->slots_needed > PLK_FUSED_SLOTS) return false;
-    const size_t lds = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE;
+    const size_t lds = (size_t)(h->tip_edge.size() + 1) * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE;
     return lds <= 150 * 1024;
 }
 
@@ -1227,8 +1244,47 @@ static int prepare_stream(plk_engine *h, bool fused)
                 me.push_back(-1);                        /* the spare matrix is all zeros */
                 if ((rc = dev_upload(h, &h->d_mat_edge, me.data(), me.size()))) return rc;
             }
-            if ((rc = dev_upload(h, &h->d_tip_edge, h->tip_edge.data(), h->tip_edge.size()))) return rc;
+            {
+                /* tip slots + one pseudo slot (edge -1) holding the raw definitions, used for
+                 * internal nodes that carry data */
+                std::vector<int> te = h->tip_edge;
+                te.push_back(-1);
+                if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
+            }
             if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
+            /* assembly interpreter: 32-bit op words {opcode | y<<3 | z<<16} in blocks of 8; an
+             * observation op carries the tip slot of the NEXT observation op (y) and the code
+             * row of the one after next (z): the prefetch chain of plk_fused4_asm.h */
+            {
+                const int ntips = (int)h->tip_edge.size();
+                std::vector<int> obs_pc, obs_t, obs_row;
+                for (int pc = 0; pc < nops; pc++) {
+                    const int code = fops[pc].x & 0xff;
+                    if (code == OP_TIP_SET || code == OP_TIP_MUL) { obs_pc.push_back(pc); obs_t.push_back(fops[pc].x >> 8); obs_row.push_back(fops[pc].y); }
+                    else if (code == OP_NODE_MUL) { obs_pc.push_back(pc); obs_t.push_back(ntips); obs_row.push_back(fops[pc].y); }
+                }
+                const int nwords = ((nops + 1 + 7) / 8) * 8 + 8;
+                std::vector<unsigned> words(nwords, (unsigned)OP_END);
+                size_t oi = 0;
+                for (int pc = 0; pc < nops; pc++) {
+                    const int code = fops[pc].x & 0xff;
+                    unsigned wv = (unsigned)code;
+                    if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                        const unsigned tn = oi + 1 < obs_t.size() ? (unsigned)obs_t[oi + 1] : 0u;
+                        const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
+                        wv = (code == OP_NODE_MUL ? (unsigned)OP_TIP_MUL : (unsigned)code) | (tn << 3) | (rn << 16);
+                        oi++;
+                    } else if (code == OP_PUSH || code == OP_POPMUL) {
+                        wv |= (unsigned)fops[pc].y << 3;
+                    }
+                    words[pc] = wv;
+                }
+                h->asm_first_tip = obs_t.empty() ? 0 : obs_t[0];
+                h->asm_first_row = obs_row.empty() ? 0 : obs_row[0];
+                h->asm_second_row = obs_row.size() > 1 ? obs_row[1] : 0;
+                h->asm_ok = h->slots_needed <= 8 && ntips + 1 < 8192 && h->obs_nodes.size() < 65536;
+                if ((rc = dev_upload(h, &h->d_words, words.data(), words.size()))) return rc;
+            }
         }
         const int nmat = (int)h->mat_edge.size();
         /* one spare matrix per category: the kernel always keeps the next matrix of the stream loaded */
@@ -1236,7 +1292,7 @@ static int prepare_stream(plk_engine *h, bool fused)
         hipLaunchKernelGGL(k_build_stream, dim3(nmat + 1, C), dim3(64), 0, h->stream,
                            h->k, K, h->E, nmat + 1, h->d_mat_edge, h->d_P, h->d_PS);
         HIPCHK(h, hipGetLastError());
-        const int ntips = (int)h->tip_edge.size();
+        const int ntips = (int)h->tip_edge.size() + 1;       /* + the pseudo slot of raw definitions */
         if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)C * ntips * h->nchar * 4))) return rc;
         hipLaunchKernelGGL(k_build_tip, dim3(ntips, C), dim3(64), 0, h->stream,
                            h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
@@ -1295,14 +1351,20 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
         FusedArgs a;
         a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size(); a.nmat = (int)h->mat_edge.size();
-        a.ntips = (int)h->tip_edge.size(); a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
+        a.ntips = (int)h->tip_edge.size() + 1; a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
         a.root_mode = h->root_mode; a.first_row = h->first_row; a.ops = h->d_fops; a.PS = h->d_PS; a.tip = h->d_tip;
         a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
         a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
         const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE * NS;
-        if (NS == 1 && h->slots_needed <= 8 && h->opt_fused_asm) {
-            hipLaunchKernelGGL(k_ll_fused4_asm, dim3(grid), dim3(PLK_TILE), lds, h->stream, a);
+        if (NS == 1 && h->asm_ok && h->opt_fused_asm) {
+            FusedAsmArgs aa;
+            aa.f = a; aa.words = h->d_words;
+            aa.first_tip = h->asm_first_tip; aa.first_row = h->asm_first_row; aa.second_row = h->asm_second_row;
+            aa.pack4 = h->nchar <= 16 ? 1 : 0;
+            const size_t lds_asm = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * (aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
+            if (h->slots_needed <= 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            else hipLaunchKernelGGL(k_ll_fused4_asm<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
         } else if (NS == 2) {
             if (h->slots_needed <= 4) launch_fused<4, 2>(h, a, grid, lds);
             else launch_fused<8, 2>(h, a, grid, lds);

@@ -1,29 +1,39 @@
 /*
- * plk_fused4_asm.h -- the k = 4 fused traversal with its interpreter loop written in
- * CDNA4 assembly (one inline-asm statement per rate category).  Included by
- * plk_engine.hip after plk_fused4.h (same FusedArgs, same program format).
+ * plk_fused4_asm.h -- the k = 4 fused traversal with its interpreter written in CDNA4
+ * assembly (one inline-asm statement per rate category).  Included by plk_engine.hip
+ * after plk_fused4.h.
  *
- * Why assembly: the loop is a wave-uniform interpreter (scalar dispatch over ~7
- * opcodes) around short vector handlers.  hipcc keeps inserting loop-carried
- * v_mov copies of the 4-vector and rebuilding branch conditions (about 2x the
- * necessary VALU and SALU instructions, measured with SQ_INSTS_VALU/SALU); here
- * every handler works in place on fixed registers:
+ * Why assembly: the loop is a wave-uniform interpreter (scalar dispatch over 6 opcodes)
+ * around short vector handlers.  hipcc inserts loop-carried v_mov copies of the 4-vector
+ * and rebuilds branch conditions (about 2x the necessary VALU and SALU instructions,
+ * measured with SQ_INSTS_VALU / SQ_INSTS_SALU); here every handler works in place on
+ * fixed registers and nothing on the critical path waits for a load issued in the same op.
  *
- *   v[24:31]  x0..x3   the partial-likelihood vector under construction (one site per lane)
- *   v[32:39]  t0..t3   temporaries (matvec partial sums, LDS / AGPR reads)
- *   v40 address temp, v41 next pattern code, v42 scale exponent, v43 temp, v44 LDS address of this lane's code column
- *   a[0:63]   stack of up to 8 waiting vectors (8 AGPRs per slot)
- *   s[36:67]  current P matrix, transposed (s[36+2(4j+i)] = P[i][j]), used as FMA scalar operands
- *   s[68:71]  next op (fetched one ahead), s72..s75 current op x,y,z + opcode
- *   s[76:77]  program pointer, s[78:79] matrix stream pointer, s[82:83] definitions table
- *   s84 LDS address of the tip table, s85 nchar*32, s86 bytes per staged code row, s87 = -1022
+ * Program format (built by prepare_stream_asm in plk_engine.hip): 32-bit op words in
+ * blocks of 8, fetched a whole block ahead with one s_load_dwordx8;
+ *   bits 2:0 opcode, bits 15:3 field y, bits 31:16 field z
+ *   MATVEC            x = P x; matrices are consumed in stream order, the next one is
+ *                     requested as soon as the current one has been used
+ *   TIP_SET / TIP_MUL x (*)= tip value of this observation, which was fetched from LDS
+ *                     during the previous observation op; y = tip slot of the NEXT
+ *                     observation op, z = code row of the one after next (prefetch chain)
+ *   PUSH / POPMUL     y = stack slot in the accumulation registers
+ *   SCALE             exact power-of-two rescale, exponent accumulated
+ *   END
+ * (an internal node with data is a TIP_MUL on the pseudo tip slot that holds the raw
+ * character definitions)
  *
- * Handlers (opcodes of plk_engine.hip):
- *   MATVEC   x = P x            16 fp64 VALU, then the next matrix of the stream is requested
- *   TIP_SET / TIP_MUL           x (*)= tip[t][code]   4 ds_read_b64 + 4 VALU; prefetches the next code
- *   PUSH d / POPMUL d           x <-> a[8d..8d+7]     8 accvgpr moves (+ 4 VALU)
- *   SCALE    x *= 2^-e, esc += e with e from the largest high word (exact)
- *   NODE_MUL x *= defs[code]    (internal node carrying data; rare)
+ * Registers:
+ *   v[24:31] x0..x3  vector under construction      v[32:39] t0..t3 temporaries
+ *   v40 address temp  v41 code of the next observation (raw)  v42 scale exponent  v43 temp
+ *   v44 LDS address of this lane's code column   v45 nibble shift  v[46:53] prefetched tip value
+ *   a[0:8D-1]  stack of D waiting vectors
+ *   s[36:67] current P (transposed), FMA scalar operands
+ *   s[68:75] current op block, s[76:83] next op block
+ *   s[84:85] program pointer, s[86:87] matrix stream pointer, s[88:89] return address,
+ *   s[90:91] dispatcher address, s92 LDS address of the tip table, s93 nchar*32,
+ *   s94 bytes per staged code row, s95 = -1022, s96 current op word, s97..s99 temps,
+ *   s35 code field width (8, or 4 when codes are packed two per byte)
  */
 #ifndef PLK_FUSED4_ASM_H
 #define PLK_FUSED4_ASM_H
@@ -42,208 +52,259 @@
     "v_accvgpr_write_b32 a" #R2 ", v26\n\tv_accvgpr_write_b32 a" #R3 ", v27\n\t"     \
     "v_accvgpr_write_b32 a" #R4 ", v28\n\tv_accvgpr_write_b32 a" #R5 ", v29\n\t"     \
     "v_accvgpr_write_b32 a" #R6 ", v30\n\tv_accvgpr_write_b32 a" #R7 ", v31\n\t"     \
-    "s_branch .Lnext_%=\n"
+    "s_setpc_b64 s[88:89]\n"
 
-/* Runs the whole program of one category for this lane's site.
- * x[4]: in = ones, out = root vector.  ch: code of the first observation op.  esc: out, scale exponent. */
-__device__ __forceinline__ void fused_run_program_asm(
-    double &x0, double &x1, double &x2, double &x3, int &esc, int ch_first,
-    const void *ops, const void *mstream, const void *defs,
-    unsigned tip_lds_addr, unsigned nchar32, unsigned tile_bytes, unsigned code_lane_addr)
+#define PLK_ASM_CALL(SREG) "s_mov_b32 s96, " #SREG "\n\ts_swappc_b64 s[88:89], s[90:91]\n\t"
+
+/* slot dispatch chains and bodies for 4 or 8 stack slots */
+#define PLK_ASM_POP_CHAIN4                                                            \
+    "s_cmp_eq_u32 s97, 0\n\ts_cbranch_scc1 .Lpop0_%=\n\t"                             \
+    "s_cmp_eq_u32 s97, 1\n\ts_cbranch_scc1 .Lpop1_%=\n\t"                             \
+    "s_cmp_eq_u32 s97, 2\n\ts_cbranch_scc1 .Lpop2_%=\n\t"
+#define PLK_ASM_POP_BODY4                                                             \
+    PLK_ASM_POP(0, 0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_POP(1, 8, 9, 10, 11, 12, 13, 14, 15)       \
+    PLK_ASM_POP(2, 16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_POP(3, 24, 25, 26, 27, 28, 29, 30, 31)
+#define PLK_ASM_PUSH_CHAIN4                                                           \
+    "s_cmp_eq_u32 s97, 0\n\ts_cbranch_scc1 .Lpush0_%=\n\t"                            \
+    "s_cmp_eq_u32 s97, 1\n\ts_cbranch_scc1 .Lpush1_%=\n\t"                            \
+    "s_cmp_eq_u32 s97, 2\n\ts_cbranch_scc1 .Lpush2_%=\n\t"
+#define PLK_ASM_PUSH_BODY4                                                            \
+    PLK_ASM_PUSH(0, 0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_PUSH(1, 8, 9, 10, 11, 12, 13, 14, 15)     \
+    PLK_ASM_PUSH(2, 16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_PUSH(3, 24, 25, 26, 27, 28, 29, 30, 31)
+
+#define PLK_ASM_SLOTS_D4_POP  PLK_ASM_POP_CHAIN4 "s_branch .Lpop3_%=\n" PLK_ASM_POP_BODY4
+#define PLK_ASM_SLOTS_D4_PUSH PLK_ASM_PUSH_CHAIN4 "s_branch .Lpush3_%=\n" PLK_ASM_PUSH_BODY4
+#define PLK_ASM_SLOTS_D8_POP                                                          \
+    PLK_ASM_POP_CHAIN4                                                                \
+    "s_cmp_eq_u32 s97, 3\n\ts_cbranch_scc1 .Lpop3_%=\n\t"                             \
+    "s_cmp_eq_u32 s97, 4\n\ts_cbranch_scc1 .Lpop4_%=\n\t"                             \
+    "s_cmp_eq_u32 s97, 5\n\ts_cbranch_scc1 .Lpop5_%=\n\t"                             \
+    "s_cmp_eq_u32 s97, 6\n\ts_cbranch_scc1 .Lpop6_%=\n\t"                             \
+    "s_branch .Lpop7_%=\n"                                                            \
+    PLK_ASM_POP_BODY4                                                                 \
+    PLK_ASM_POP(4, 32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_POP(5, 40, 41, 42, 43, 44, 45, 46, 47) \
+    PLK_ASM_POP(6, 48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_POP(7, 56, 57, 58, 59, 60, 61, 62, 63)
+#define PLK_ASM_SLOTS_D8_PUSH                                                         \
+    PLK_ASM_PUSH_CHAIN4                                                               \
+    "s_cmp_eq_u32 s97, 3\n\ts_cbranch_scc1 .Lpush3_%=\n\t"                            \
+    "s_cmp_eq_u32 s97, 4\n\ts_cbranch_scc1 .Lpush4_%=\n\t"                            \
+    "s_cmp_eq_u32 s97, 5\n\ts_cbranch_scc1 .Lpush5_%=\n\t"                            \
+    "s_cmp_eq_u32 s97, 6\n\ts_cbranch_scc1 .Lpush6_%=\n\t"                            \
+    "s_branch .Lpush7_%=\n"                                                           \
+    PLK_ASM_PUSH_BODY4                                                                \
+    PLK_ASM_PUSH(4, 32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_PUSH(5, 40, 41, 42, 43, 44, 45, 46, 47) \
+    PLK_ASM_PUSH(6, 48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_PUSH(7, 56, 57, 58, 59, 60, 61, 62, 63)
+
+#define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS)                                        \
+        /* ---- prologue: operands into the fixed registers ---- */                   \
+        "v_mov_b32 v24, %[x0lo]\n\tv_mov_b32 v25, %[x0hi]\n\t"                        \
+        "v_mov_b32 v26, %[x1lo]\n\tv_mov_b32 v27, %[x1hi]\n\t"                        \
+        "v_mov_b32 v28, %[x2lo]\n\tv_mov_b32 v29, %[x2hi]\n\t"                        \
+        "v_mov_b32 v30, %[x3lo]\n\tv_mov_b32 v31, %[x3hi]\n\t"                        \
+        "v_mov_b32 v42, 0\n\t"                                                        \
+        "v_mov_b32 v44, %[clane]\n\t"                                                 \
+        "v_mov_b32 v45, %[nshift]\n\t"                                                \
+        "s_mov_b64 s[84:85], %[ops]\n\t"                                              \
+        "s_mov_b64 s[86:87], %[mstream]\n\t"                                          \
+        "s_mov_b32 s92, %[tipbase]\n\t"                                               \
+        "s_mov_b32 s93, %[nchar32]\n\t"                                               \
+        "s_mov_b32 s94, %[tile]\n\t"                                                  \
+        "s_mov_b32 s35, %[cwidth]\n\t"                                               \
+        "s_movk_i32 s95, 0xfc02\n\t"                                                  \
+        "s_load_dwordx8 s[68:75], s[84:85], 0x0\n\t"                                  \
+        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
+        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
+        /* prefetch chain start: tip value of the first observation, code of the second */ \
+        "v_bfe_u32 v43, %[ch], v45, s35\n\t"                                         \
+        "v_lshl_add_u32 v40, v43, 5, %[firsttip]\n\t"                                 \
+        "ds_read_b64 v[46:47], v40\n\t"                                               \
+        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
+        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
+        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
+        "ds_read_u8 v41, %[secaddr]\n\t"                                              \
+        "s_getpc_b64 s[90:91]\n"                                                      \
+        ".Lpcref_%=:\n\t"                                                             \
+        "s_add_u32 s90, s90, .Ldispatch_%=-.Lpcref_%=\n\t"                            \
+        "s_addc_u32 s91, s91, 0\n\t"                                                  \
+        "s_waitcnt lgkmcnt(0)\n"                                                      \
+        /* ---- one block of 8 ops per iteration; the next block is already in flight ---- */ \
+        ".Lblock_%=:\n\t"                                                             \
+        "s_load_dwordx8 s[76:83], s[84:85], 0x20\n\t"                                 \
+        "s_add_u32 s84, s84, 32\n\t"                                                  \
+        "s_addc_u32 s85, s85, 0\n\t"                                                  \
+        PLK_ASM_CALL(s68) PLK_ASM_CALL(s69) PLK_ASM_CALL(s70) PLK_ASM_CALL(s71)       \
+        PLK_ASM_CALL(s72) PLK_ASM_CALL(s73) PLK_ASM_CALL(s74) PLK_ASM_CALL(s75)       \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "s_mov_b64 s[68:69], s[76:77]\n\t"                                            \
+        "s_mov_b64 s[70:71], s[78:79]\n\t"                                            \
+        "s_mov_b64 s[72:73], s[80:81]\n\t"                                            \
+        "s_mov_b64 s[74:75], s[82:83]\n\t"                                            \
+        "s_branch .Lblock_%=\n"                                                       \
+        /* ---- dispatcher: s96 = op word ---- */                                     \
+        ".Ldispatch_%=:\n\t"                                                          \
+        "s_and_b32 s97, s96, 7\n\t"                                                   \
+        "s_cmp_eq_u32 s97, 2\n\t"                                                     \
+        "s_cbranch_scc1 .Lmatvec_%=\n\t"                                              \
+        "s_cmp_lt_u32 s97, 2\n\t"                                                     \
+        "s_cbranch_scc1 .Ltip_%=\n\t"                                                 \
+        "s_cmp_eq_u32 s97, 4\n\t"                                                     \
+        "s_cbranch_scc1 .Lpop_%=\n\t"                                                 \
+        "s_cmp_eq_u32 s97, 3\n\t"                                                     \
+        "s_cbranch_scc1 .Lpush_%=\n\t"                                                \
+        "s_cmp_eq_u32 s97, 6\n\t"                                                     \
+        "s_cbranch_scc1 .Lscale_%=\n\t"                                               \
+        "s_branch .Ldone_%=\n"                                                        \
+        /* ---- MATVEC: x = M x in place ---- */                                      \
+        ".Lmatvec_%=:\n\t"                                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
+        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
+        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
+        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"                        \
+        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
+        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
+        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
+        "s_add_u32 s86, s86, 0x80\n\t"                                                \
+        "s_addc_u32 s87, s87, 0\n\t"                                                  \
+        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
+        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
+        "s_setpc_b64 s[88:89]\n"                                                      \
+        /* ---- TIP_SET / TIP_MUL: consume the prefetched value, start the next fetches ---- */ \
+        ".Ltip_%=:\n\t"                                                               \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "s_cmp_eq_u32 s97, 0\n\t"                                                     \
+        "s_cbranch_scc1 .Ltipset_%=\n\t"                                              \
+        "v_mul_f64 v[24:25], v[24:25], v[46:47]\n\t"                                  \
+        "v_mul_f64 v[26:27], v[26:27], v[48:49]\n\t"                                  \
+        "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
+        "v_mul_f64 v[30:31], v[30:31], v[52:53]\n\t"                                  \
+        "s_branch .Ltipnext_%=\n"                                                     \
+        ".Ltipset_%=:\n\t"                                                            \
+        "v_mov_b64 v[24:25], v[46:47]\n\t"                                            \
+        "v_mov_b64 v[26:27], v[48:49]\n\t"                                            \
+        "v_mov_b64 v[28:29], v[50:51]\n\t"                                            \
+        "v_mov_b64 v[30:31], v[52:53]\n"                                              \
+        ".Ltipnext_%=:\n\t"                                                           \
+        "s_bfe_u32 s98, s96, 0xd0003\n\t"                                             \
+        "s_mul_i32 s98, s98, s93\n\t"                                                 \
+        "s_add_u32 s98, s98, s92\n\t"                                                 \
+        "s_lshr_b32 s99, s96, 16\n\t"                                                 \
+        "s_mul_i32 s99, s99, s94\n\t"                                                 \
+        "v_bfe_u32 v43, v41, v45, s35\n\t"                                           \
+        "v_lshl_add_u32 v40, v43, 5, s98\n\t"                                         \
+        "ds_read_b64 v[46:47], v40\n\t"                                               \
+        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
+        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
+        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
+        "v_add_u32 v43, s99, v44\n\t"                                                 \
+        "ds_read_u8 v41, v43\n\t"                                                     \
+        "s_setpc_b64 s[88:89]\n"                                                      \
+        /* ---- POPMUL d ---- */                                                      \
+        ".Lpop_%=:\n\t"                                                               \
+        "s_bfe_u32 s97, s96, 0xd0003\n\t"                                             \
+        POP_SLOTS                                                                     \
+        ".Lpopmul_%=:\n\t"                                                            \
+        "v_mul_f64 v[24:25], v[24:25], v[32:33]\n\t"                                  \
+        "v_mul_f64 v[26:27], v[26:27], v[34:35]\n\t"                                  \
+        "v_mul_f64 v[28:29], v[28:29], v[36:37]\n\t"                                  \
+        "v_mul_f64 v[30:31], v[30:31], v[38:39]\n\t"                                  \
+        "s_setpc_b64 s[88:89]\n"                                                      \
+        /* ---- PUSH d ---- */                                                        \
+        ".Lpush_%=:\n\t"                                                              \
+        "s_bfe_u32 s97, s96, 0xd0003\n\t"                                             \
+        PUSH_SLOTS                                                                    \
+        /* ---- SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */ \
+        ".Lscale_%=:\n\t"                                                             \
+        "v_max_u32 v43, v25, v27\n\t"                                                 \
+        "v_max3_u32 v43, v29, v31, v43\n\t"                                           \
+        "v_lshrrev_b32 v43, 20, v43\n\t"                                              \
+        "v_sub_u32 v40, 0x3fe, v43\n\t"                                               \
+        "v_ldexp_f64 v[24:25], v[24:25], v40\n\t"                                     \
+        "v_ldexp_f64 v[26:27], v[26:27], v40\n\t"                                     \
+        "v_ldexp_f64 v[28:29], v[28:29], v40\n\t"                                     \
+        "v_ldexp_f64 v[30:31], v[30:31], v40\n\t"                                     \
+        "v_add3_u32 v42, v42, v43, s95\n\t"                                           \
+        "s_setpc_b64 s[88:89]\n"                                                      \
+        /* ---- epilogue ---- */                                                      \
+        ".Ldone_%=:\n\t"                                                              \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                           \
+        "v_mov_b32 %[x0lo], v24\n\tv_mov_b32 %[x0hi], v25\n\t"                        \
+        "v_mov_b32 %[x1lo], v26\n\tv_mov_b32 %[x1hi], v27\n\t"                        \
+        "v_mov_b32 %[x2lo], v28\n\tv_mov_b32 %[x2hi], v29\n\t"                        \
+        "v_mov_b32 %[x3lo], v30\n\tv_mov_b32 %[x3hi], v31\n\t"                        \
+        "v_mov_b32 %[esc], v42\n\t"                                                   \
+        "s_nop 1"
+
+#define PLK_ASM_OPERANDS                                                              \
+        : [x0lo] "+v"(x0lo), [x0hi] "+v"(x0hi), [x1lo] "+v"(x1lo), [x1hi] "+v"(x1hi), \
+          [x2lo] "+v"(x2lo), [x2hi] "+v"(x2hi), [x3lo] "+v"(x3lo), [x3hi] "+v"(x3hi), [esc] "=v"(esc) \
+        : [ch] "v"(p.ch_first), [clane] "v"(p.code_lane_addr), [nshift] "v"(p.nibble_shift),          \
+          [secaddr] "v"(p.second_code_addr), [ops] "s"(p.ops), [mstream] "s"(p.mstream),              \
+          [tipbase] "s"(p.tip_lds_addr), [nchar32] "s"(p.nchar32), [tile] "s"(p.row_bytes),           \
+          [cwidth] "s"(p.code_width), [firsttip] "s"(p.first_tip_addr)
+
+#define PLK_ASM_CLOBBERS_COMMON                                                       \
+          "memory", "scc", "vcc",                                                     \
+          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", \
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",               \
+          "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", \
+          "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s35"
+
+struct FusedAsmParams {
+    const void *ops;            /* this program: op words in blocks of 8 */
+    const void *mstream;        /* matrix stream of the category */
+    unsigned tip_lds_addr;      /* LDS byte address of the tip table */
+    unsigned nchar32;           /* bytes per tip slot = nchar * 32 */
+    unsigned row_bytes;         /* bytes per staged code row */
+    unsigned code_width;        /* 8, or 4 when two codes share a byte */
+    unsigned first_tip_addr;    /* tip_lds_addr + first tip slot * nchar32 */
+    unsigned code_lane_addr;    /* LDS byte address of this lane's byte in row 0 */
+    unsigned nibble_shift;      /* 0, or 4 for odd lanes when packed */
+    unsigned second_code_addr;  /* LDS byte address of the code of the second observation op */
+    int ch_first;               /* raw code byte of the first observation op */
+};
+
+/* Runs the whole program of one category for this lane's site: x = ones in, root vector out. */
+template <int D>
+__device__ __forceinline__ void fused_run_program_asm(double &x0, double &x1, double &x2, double &x3, int &esc,
+                                                       const FusedAsmParams &p)
 {
     int x0lo = __double2loint(x0), x0hi = __double2hiint(x0), x1lo = __double2loint(x1), x1hi = __double2hiint(x1);
     int x2lo = __double2loint(x2), x2hi = __double2hiint(x2), x3lo = __double2loint(x3), x3hi = __double2hiint(x3);
-    asm volatile(
-        /* ---- prologue: operands into the fixed registers ---- */
-        "v_mov_b32 v24, %[x0lo]\n\tv_mov_b32 v25, %[x0hi]\n\t"
-        "v_mov_b32 v26, %[x1lo]\n\tv_mov_b32 v27, %[x1hi]\n\t"
-        "v_mov_b32 v28, %[x2lo]\n\tv_mov_b32 v29, %[x2hi]\n\t"
-        "v_mov_b32 v30, %[x3lo]\n\tv_mov_b32 v31, %[x3hi]\n\t"
-        "v_mov_b32 v41, %[ch]\n\t"
-        "v_mov_b32 v42, 0\n\t"
-        "v_mov_b32 v44, %[clane]\n\t"
-        "s_mov_b64 s[76:77], %[ops]\n\t"
-        "s_mov_b64 s[78:79], %[mstream]\n\t"
-        "s_mov_b64 s[82:83], %[defs]\n\t"
-        "s_mov_b32 s84, %[tipbase]\n\t"
-        "s_mov_b32 s85, %[nchar32]\n\t"
-        "s_mov_b32 s86, %[tile]\n\t"
-        "s_movk_i32 s87, 0xfc02\n\t"
-        "s_load_dwordx4 s[72:75], s[76:77], 0x0\n\t"
-        "s_load_dwordx16 s[36:51], s[78:79], 0x0\n\t"
-        "s_load_dwordx16 s[52:67], s[78:79], 0x40\n\t"
-        "s_waitcnt lgkmcnt(0)\n"
-        /* ---- dispatch ---- */
-        ".Lloop_%=:\n\t"
-        "s_load_dwordx4 s[68:71], s[76:77], 0x10\n\t"
-        "s_add_u32 s76, s76, 16\n\t"
-        "s_addc_u32 s77, s77, 0\n\t"
-        "s_and_b32 s75, s72, 0xff\n\t"
-        "s_cmp_eq_u32 s75, 2\n\t"
-        "s_cbranch_scc1 .Lmatvec_%=\n\t"
-        "s_cmp_lt_u32 s75, 2\n\t"
-        "s_cbranch_scc1 .Ltip_%=\n\t"
-        "s_cmp_eq_u32 s75, 4\n\t"
-        "s_cbranch_scc1 .Lpop_%=\n\t"
-        "s_cmp_eq_u32 s75, 3\n\t"
-        "s_cbranch_scc1 .Lpush_%=\n\t"
-        "s_cmp_eq_u32 s75, 6\n\t"
-        "s_cbranch_scc1 .Lscale_%=\n\t"
-        "s_cmp_eq_u32 s75, 5\n\t"
-        "s_cbranch_scc1 .Lnode_%=\n\t"
-        "s_branch .Ldone_%=\n"
-        /* ---- MATVEC: x = M x in place ---- */
-        ".Lmatvec_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"
-        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"
-        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"
-        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"
-        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"
-        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"
-        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"
-        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"
-        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"
-        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"
-        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"
-        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"
-        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"
-        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"
-        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"
-        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"
-        "s_add_u32 s78, s78, 0x80\n\t"
-        "s_addc_u32 s79, s79, 0\n\t"
-        "s_load_dwordx16 s[36:51], s[78:79], 0x0\n\t"
-        "s_load_dwordx16 s[52:67], s[78:79], 0x40\n\t"
-        "s_branch .Lnext_%=\n"
-        /* ---- TIP_SET / TIP_MUL ---- */
-        ".Ltip_%=:\n\t"
-        "s_lshr_b32 s80, s72, 8\n\t"
-        "s_mul_i32 s80, s80, s85\n\t"
-        "s_add_u32 s80, s80, s84\n\t"
-        "s_mul_i32 s81, s74, s86\n\t"
-        "v_lshl_add_u32 v40, v41, 5, s80\n\t"
-        "ds_read_b64 v[32:33], v40\n\t"
-        "ds_read_b64 v[34:35], v40 offset:8\n\t"
-        "ds_read_b64 v[36:37], v40 offset:16\n\t"
-        "ds_read_b64 v[38:39], v40 offset:24\n\t"
-        "v_add_u32 v43, s81, v44\n\t"
-        "ds_read_u8 v41, v43\n\t"
-        "s_cmp_eq_u32 s75, 0\n\t"
-        "s_cbranch_scc1 .Ltipset_%=\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f64 v[24:25], v[24:25], v[32:33]\n\t"
-        "v_mul_f64 v[26:27], v[26:27], v[34:35]\n\t"
-        "v_mul_f64 v[28:29], v[28:29], v[36:37]\n\t"
-        "v_mul_f64 v[30:31], v[30:31], v[38:39]\n\t"
-        "s_branch .Lnext_%=\n"
-        ".Ltipset_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mov_b64 v[24:25], v[32:33]\n\t"
-        "v_mov_b64 v[26:27], v[34:35]\n\t"
-        "v_mov_b64 v[28:29], v[36:37]\n\t"
-        "v_mov_b64 v[30:31], v[38:39]\n\t"
-        "s_branch .Lnext_%=\n"
-        /* ---- POPMUL d ---- */
-        ".Lpop_%=:\n\t"
-        "s_cmp_eq_u32 s73, 0\n\ts_cbranch_scc1 .Lpop0_%=\n\t"
-        "s_cmp_eq_u32 s73, 1\n\ts_cbranch_scc1 .Lpop1_%=\n\t"
-        "s_cmp_eq_u32 s73, 2\n\ts_cbranch_scc1 .Lpop2_%=\n\t"
-        "s_cmp_eq_u32 s73, 3\n\ts_cbranch_scc1 .Lpop3_%=\n\t"
-        "s_cmp_eq_u32 s73, 4\n\ts_cbranch_scc1 .Lpop4_%=\n\t"
-        "s_cmp_eq_u32 s73, 5\n\ts_cbranch_scc1 .Lpop5_%=\n\t"
-        "s_cmp_eq_u32 s73, 6\n\ts_cbranch_scc1 .Lpop6_%=\n\t"
-        "s_branch .Lpop7_%=\n"
-        PLK_ASM_POP(0, 0, 1, 2, 3, 4, 5, 6, 7)
-        PLK_ASM_POP(1, 8, 9, 10, 11, 12, 13, 14, 15)
-        PLK_ASM_POP(2, 16, 17, 18, 19, 20, 21, 22, 23)
-        PLK_ASM_POP(3, 24, 25, 26, 27, 28, 29, 30, 31)
-        PLK_ASM_POP(4, 32, 33, 34, 35, 36, 37, 38, 39)
-        PLK_ASM_POP(5, 40, 41, 42, 43, 44, 45, 46, 47)
-        PLK_ASM_POP(6, 48, 49, 50, 51, 52, 53, 54, 55)
-        PLK_ASM_POP(7, 56, 57, 58, 59, 60, 61, 62, 63)
-        ".Lpopmul_%=:\n\t"
-        "v_mul_f64 v[24:25], v[24:25], v[32:33]\n\t"
-        "v_mul_f64 v[26:27], v[26:27], v[34:35]\n\t"
-        "v_mul_f64 v[28:29], v[28:29], v[36:37]\n\t"
-        "v_mul_f64 v[30:31], v[30:31], v[38:39]\n\t"
-        "s_branch .Lnext_%=\n"
-        /* ---- PUSH d ---- */
-        ".Lpush_%=:\n\t"
-        "s_cmp_eq_u32 s73, 0\n\ts_cbranch_scc1 .Lpush0_%=\n\t"
-        "s_cmp_eq_u32 s73, 1\n\ts_cbranch_scc1 .Lpush1_%=\n\t"
-        "s_cmp_eq_u32 s73, 2\n\ts_cbranch_scc1 .Lpush2_%=\n\t"
-        "s_cmp_eq_u32 s73, 3\n\ts_cbranch_scc1 .Lpush3_%=\n\t"
-        "s_cmp_eq_u32 s73, 4\n\ts_cbranch_scc1 .Lpush4_%=\n\t"
-        "s_cmp_eq_u32 s73, 5\n\ts_cbranch_scc1 .Lpush5_%=\n\t"
-        "s_cmp_eq_u32 s73, 6\n\ts_cbranch_scc1 .Lpush6_%=\n\t"
-        "s_branch .Lpush7_%=\n"
-        PLK_ASM_PUSH(0, 0, 1, 2, 3, 4, 5, 6, 7)
-        PLK_ASM_PUSH(1, 8, 9, 10, 11, 12, 13, 14, 15)
-        PLK_ASM_PUSH(2, 16, 17, 18, 19, 20, 21, 22, 23)
-        PLK_ASM_PUSH(3, 24, 25, 26, 27, 28, 29, 30, 31)
-        PLK_ASM_PUSH(4, 32, 33, 34, 35, 36, 37, 38, 39)
-        PLK_ASM_PUSH(5, 40, 41, 42, 43, 44, 45, 46, 47)
-        PLK_ASM_PUSH(6, 48, 49, 50, 51, 52, 53, 54, 55)
-        PLK_ASM_PUSH(7, 56, 57, 58, 59, 60, 61, 62, 63)
-        /* ---- SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */
-        ".Lscale_%=:\n\t"
-        "v_max_u32 v43, v25, v27\n\t"
-        "v_max3_u32 v43, v29, v31, v43\n\t"
-        "v_lshrrev_b32 v43, 20, v43\n\t"
-        "v_sub_u32 v40, 0x3fe, v43\n\t"
-        "v_ldexp_f64 v[24:25], v[24:25], v40\n\t"
-        "v_ldexp_f64 v[26:27], v[26:27], v40\n\t"
-        "v_ldexp_f64 v[28:29], v[28:29], v40\n\t"
-        "v_ldexp_f64 v[30:31], v[30:31], v40\n\t"
-        "v_add3_u32 v42, v42, v43, s87\n\t"
-        "s_branch .Lnext_%=\n"
-        /* ---- NODE_MUL: x *= defs[code] (definitions in global memory) ---- */
-        ".Lnode_%=:\n\t"
-        "v_lshlrev_b32 v40, 5, v41\n\t"
-        "global_load_dwordx2 v[32:33], v40, s[82:83]\n\t"
-        "global_load_dwordx2 v[34:35], v40, s[82:83] offset:8\n\t"
-        "global_load_dwordx2 v[36:37], v40, s[82:83] offset:16\n\t"
-        "global_load_dwordx2 v[38:39], v40, s[82:83] offset:24\n\t"
-        "s_mul_i32 s81, s74, s86\n\t"
-        "v_add_u32 v43, s81, v44\n\t"
-        "ds_read_u8 v41, v43\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "s_branch .Lpopmul_%=\n"
-        /* ---- next op ---- */
-        ".Lnext_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 s[72:73], s[68:69]\n\t"
-        "s_mov_b32 s74, s70\n\t"
-        "s_branch .Lloop_%=\n"
-        /* ---- epilogue ---- */
-        ".Ldone_%=:\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "v_mov_b32 %[x0lo], v24\n\tv_mov_b32 %[x0hi], v25\n\t"
-        "v_mov_b32 %[x1lo], v26\n\tv_mov_b32 %[x1hi], v27\n\t"
-        "v_mov_b32 %[x2lo], v28\n\tv_mov_b32 %[x2hi], v29\n\t"
-        "v_mov_b32 %[x3lo], v30\n\tv_mov_b32 %[x3hi], v31\n\t"
-        "v_mov_b32 %[esc], v42\n\t"
-        "s_nop 1"
-        : [x0lo] "+v"(x0lo), [x0hi] "+v"(x0hi), [x1lo] "+v"(x1lo), [x1hi] "+v"(x1hi),
-          [x2lo] "+v"(x2lo), [x2hi] "+v"(x2hi), [x3lo] "+v"(x3lo), [x3hi] "+v"(x3hi), [esc] "=v"(esc)
-        : [ch] "v"(ch_first), [clane] "v"(code_lane_addr), [ops] "s"(ops), [mstream] "s"(mstream), [defs] "s"(defs),
-          [tipbase] "s"(tip_lds_addr), [nchar32] "s"(nchar32), [tile] "s"(tile_bytes)
-        : "memory", "scc", "vcc",
-          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
-          "v40", "v41", "v42", "v43", "v44",
-          "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
-          "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",
-          "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
-          "s84", "s85", "s86", "s87",
-          PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
+    if constexpr (D <= 4) {
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH)
+                     PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31);
+    } else {
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH)
+                     PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
+    }
     x0 = __hiloint2double(x0hi, x0lo); x1 = __hiloint2double(x1hi, x1lo);
     x2 = __hiloint2double(x2hi, x2lo); x3 = __hiloint2double(x3hi, x3lo);
 }
 
-/* same staging, category loop and epilogue as k_ll_fused4<8,1>, with the program run in assembly */
-__global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedArgs a)
+struct FusedAsmArgs {
+    FusedArgs f;                /* S, Spad, C, nmat, ntips (incl. the pseudo slot), nchar, nobs, root_mode, codes, ... */
+    const unsigned *words;      /* op words, blocks of 8, END padded, one spare block */
+    int first_tip, first_row, second_row;
+    int pack4;                  /* two codes per staged byte (nchar <= 16) */
+};
+
+/* staging, category loop and epilogue in C++, the program run in assembly */
+template <int D>
+__global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedAsmArgs aa)
 {
+    const FusedArgs &a = aa.f;
     extern __shared__ double lds_dyn[];
     double *tip_lds = lds_dyn;
     const int tip_doubles = a.ntips * a.nchar * 4;
@@ -251,19 +312,35 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedArgs a)
     const long tile0 = (long)blockIdx.x * PLK_TILE;
     const int tid = threadIdx.x;
     const long s = tile0 + tid;
+    const int row_bytes = aa.pack4 ? PLK_TILE / 2 : PLK_TILE;
     {
+        /* each thread moves 4 codes of one row: one dword in, one dword (or one 16-bit pair) out */
         const int ndw = a.nobs * (PLK_TILE / 4);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
         for (int idx = tid; idx < ndw; idx += PLK_TILE) {
-            int row = idx >> 6, col = idx & 63;
+            const int row = idx >> 6, col = idx & 63;
             const uint32_t *src = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad + tile0);
-            dst[idx] = src[col];
+            const uint32_t q = src[col];
+            if (aa.pack4) {
+                const uint32_t packed = (q & 0xf) | ((q >> 4) & 0xf0) | ((q >> 8) & 0xf00) | ((q >> 12) & 0xf000);
+                reinterpret_cast<uint16_t *>(code_lds)[row * (PLK_TILE / 4) + col] = (uint16_t)packed;
+            } else {
+                reinterpret_cast<uint32_t *>(code_lds)[idx] = q;
+            }
         }
     }
     const PLK_AS4 double *prior = as_uniform(a.cat_prior);
     const PLK_AS4 double *rootw = as_uniform(a.root_w);
-    const unsigned tip_addr = (unsigned)(size_t)tip_lds;
-    const unsigned lane_addr = (unsigned)(size_t)(code_lds + tid);
+
+    FusedAsmParams p;
+    p.ops = aa.words;
+    p.tip_lds_addr = (unsigned)(size_t)tip_lds;
+    p.nchar32 = (unsigned)a.nchar * 32u;
+    p.row_bytes = (unsigned)row_bytes;
+    p.code_width = aa.pack4 ? 4u : 8u;
+    p.first_tip_addr = p.tip_lds_addr + (unsigned)aa.first_tip * p.nchar32;
+    p.code_lane_addr = (unsigned)(size_t)code_lds + (aa.pack4 ? (unsigned)(tid >> 1) : (unsigned)tid);
+    p.nibble_shift = aa.pack4 ? (unsigned)(tid & 1) * 4u : 0u;
+    p.second_code_addr = p.code_lane_addr + (unsigned)aa.second_row * (unsigned)row_bytes;
 
     double sum = 0.0;
     int Eexp = 0;
@@ -278,9 +355,9 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedArgs a)
         __syncthreads();
         double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
         int esc = 0;
-        const int ch_first = code_lds[a.first_row * PLK_TILE + tid];
-        fused_run_program_asm(x0, x1, x2, x3, esc, ch_first, a.ops, a.PS + (size_t)c * (a.nmat + 1) * 16, a.defs,
-                              tip_addr, (unsigned)a.nchar * 32u, (unsigned)PLK_TILE, lane_addr);
+        p.mstream = a.PS + (size_t)c * (a.nmat + 1) * 16;
+        p.ch_first = code_lds[(p.code_lane_addr - (unsigned)(size_t)code_lds) + aa.first_row * row_bytes];
+        fused_run_program_asm<D>(x0, x1, x2, x3, esc, p);
         double lh;
         if (a.root_mode == PLK_ROOT_NONE) lh = ((x0 + x1) + x2) + x3;
         else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((x0 + x1) + x2) + x3) * 0.25;
