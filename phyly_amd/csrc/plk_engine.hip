@@ -102,6 +102,9 @@ struct plk_engine {
     int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr;
     double *d_PS = nullptr;              /* [C][nops][K*K] transposed: PS[j*K+i] = P[i][j] */
     double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
+    double *d_frag = nullptr; size_t frag_cap = 0;   /* MFMA A fragments */
+    double *d_root_wd = nullptr;         /* root weights, distributed layout */
+    bool mfma_dirty = true;
     size_t ps_cap = 0, tip_cap = 0;
 
     /* workspaces */
@@ -111,7 +114,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0;
 };
 
@@ -384,6 +387,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
+#include "plk_mfma.h"
 
 /* ====================================================================== */
 /* K2+K3 generic: any k <= K, stack slots in HBM                           */
@@ -856,7 +860,7 @@ extern "C" void plk_destroy(plk_engine *h)
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
                     h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
-                    h->d_PS, h->d_tip, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -875,6 +879,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
     if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; return PLK_OK; }
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; return PLK_OK; }
+    if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1201,6 +1206,12 @@ static int fused_sites_per_lane(const plk_engine *h)
     return 1;   /* the assembly interpreter (one site per lane) is the fastest variant measured */
 }
 
+/* fp64 matrix-core kernel: larger state spaces with compact codes */
+static bool use_mfma(const plk_engine *h)
+{
+    return !h->opt_force_generic && h->opt_mfma && h->pat_mode == 1 && h->k >= 9 && h->k <= 64;
+}
+
 static bool use_fused(const plk_engine *h)
 {
     if (h->opt_force_generic) return false;
@@ -1333,8 +1344,10 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
     const bool fused = use_fused(h);
-    if (h->stream_dirty || (long)(fused ? 1 : 2) != h->info_ll_kernel) {
+    const long kind = fused ? 1 : (use_mfma(h) ? 3 : 2);
+    if (h->stream_dirty || kind != h->info_ll_kernel) {
         h->stream_dirty = true;
+        h->mfma_dirty = true;
         if ((rc = prepare_stream(h, fused))) return rc;
     }
     const long S = h->S;
@@ -1374,6 +1387,44 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
             else launch_fused<16, 1>(h, a, grid, lds);
         }
         h->info_ll_kernel = 1;
+    } else if (use_mfma(h)) {
+        /* 9 <= k <= 64 with compact codes: fp64 matrix-core kernel (plk_mfma.h) */
+        const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
+        const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
+        grid = (unsigned)((S + MF_SITES - 1) / MF_SITES);
+        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        const long slot_stride = (long)grid * MF_SITES * 4;
+        const int nslots = std::max(h->slots_needed, 1);
+        if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * R * slot_stride))) return rc;
+        if (h->mfma_dirty) {
+            std::vector<int> te = h->tip_edge;
+            te.push_back(-1);
+            if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
+            std::vector<double> rwd((size_t)4 * R, 0.0);
+            for (int i = 0; i < h->k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
+            if ((rc = dev_upload(h, &h->d_root_wd, rwd.data(), rwd.size()))) return rc;
+            if ((rc = dev_reserve(h, &h->d_frag, &h->frag_cap, (size_t)h->C * nops * T * kk4 * 64))) return rc;
+            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4 * R))) return rc;
+            hipLaunchKernelGGL(k_build_frag, dim3(nops, h->C), dim3(256), 0, h->stream,
+                               h->k, T, kk4, h->E, nops, h->d_op_edge, h->d_P, h->d_frag);
+            hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, h->C), dim3(256), 0, h->stream,
+                               h->k, R, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->K, h->d_tip);
+            HIPCHK(h, hipGetLastError());
+            h->mfma_dirty = false;
+        }
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        MfmaArgs a;
+        a.S = S; a.Spad = h->Spad; a.k = h->k; a.kk4 = kk4; a.C = h->C; a.nops = nops; a.ntips = ntips;
+        a.nchar = h->nchar; a.root_mode = h->root_mode; a.ops = h->d_ops; a.frag = h->d_frag; a.tip = h->d_tip;
+        a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
+        a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
+        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
+        if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else if (T == 3) hipLaunchKernelGGL(k_ll_mfma<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_ll_mfma<4>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        h->info_ll_kernel = 3;
     } else {
         grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);
         if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }

@@ -1,0 +1,207 @@
+/*
+ * plk_mfma.h -- K2+K3 for larger state spaces (9 <= k <= 64: amino acids, codons) on the
+ * fp64 matrix cores.  Included by plk_engine.hip.
+ *
+ * For k = 20 or 61 the per-edge update L <- P_e L is a (k x k) x (k x sites) product with
+ * arithmetic intensity above the fp64 ridge, so it is compute bound and GEMM shaped: it
+ * goes on v_mfma_f64_16x16x4_f64.  Layout (MI355X guide, "f64 MFMA"):
+ *     A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
+ *     D: lane l holds D[row (l>>4) + 4 r][col l&15] in result register r = 0..3
+ * A wavefront owns 16 sites (columns); a site's partial vector is spread over the 4 lanes
+ * {s, s+16, s+32, s+48}: lane group g = l>>4 holds states g, g+4, g+8, ... in registers.
+ * With that layout the D tile t, register r of one product IS the B operand of k-step
+ * 4t + r of the next product: chained matrix-vector products need no lane movement.
+ * P_e is pre-arranged in "A fragments" (64 doubles per (row tile, k-step), lane order)
+ * and staged through LDS once per op for the whole workgroup.
+ *
+ * The traversal program is the same post-order program as the other ll kernels
+ * (OP_* in plk_engine.hip); stack slots live in HBM in the same distributed layout;
+ * leaves use tip tables P_e * defs[code] (built in double-double) gathered from L2.
+ *
+ * Replaces: src/arbplfll.c:139-170 x src/evaluate_site_lhood.c:21-57 x src/util.c:242-301.
+ */
+#ifndef PLK_MFMA_H
+#define PLK_MFMA_H
+
+typedef double plk_d4 __attribute__((ext_vector_type(4)));
+
+#define MF_BLOCK 256           /* 4 waves = 64 sites per workgroup */
+#define MF_SITES 64
+
+struct MfmaArgs {
+    long S, Spad;
+    int k, kk4, C, nops, ntips, nchar, root_mode;
+    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot */
+    const double *frag;       /* [C][nops][T][kk4][64] A fragments of P (zero padded) */
+    const double *tip;        /* [C][ntips+1][nchar][4][4T]: [lane group][register], last slot = raw definitions */
+    const uint8_t *codes;     /* [N][Spad] */
+    const double *cat_prior;
+    const double *root_wd;    /* [4][4T] root weights in the distributed layout */
+    const double *w;
+    double *slots;            /* [nslots][4T][Spad4] with Spad4 = 4 * padded sites (lane-linear) */
+    long slot_stride;         /* doubles per (slot, register) plane */
+    double *site_ll;
+    dd *partial;
+};
+
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
+{
+    extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles */
+    constexpr int R = 4 * T;                      /* registers (states) per lane */
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;                      /* lane group = state residue mod 4 */
+    const long site = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
+    const bool valid = site < a.S;
+    const long sc = valid ? site : a.S - 1;
+    const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;   /* lane-linear index for slots */
+    const int nfrag = T * a.kk4 * 64;
+
+    double sum = 0.0;
+    int Eexp = 0;
+    bool have = false;
+
+    for (int c = 0; c < a.C; c++) {
+        double x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = 1.0;
+        int esc = 0;
+        for (int pc = 0; pc < a.nops; pc++) {
+            const int2 op = a.ops[pc];
+            const int code = op.x & 0xff;
+            if (code == OP_MATVEC) {
+                /* stage the A fragments of this edge (same for all 4 waves) */
+                __syncthreads();
+                const double *src = a.frag + ((size_t)c * a.nops + pc) * nfrag;
+                for (int i = tid; i < nfrag / 2; i += MF_BLOCK)
+                    reinterpret_cast<double2 *>(lds_frag)[i] = reinterpret_cast<const double2 *>(src)[i];
+                __syncthreads();
+                plk_d4 acc[T];
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t] = (plk_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if (q < a.kk4) {
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const double af = lds_frag[(t * a.kk4 + q) * 64 + lane];
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, x[q], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    x[4 * t + 0] = acc[t][0]; x[4 * t + 1] = acc[t][1];
+                    x[4 * t + 2] = acc[t][2]; x[4 * t + 3] = acc[t][3];
+                }
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (op.x >> 8);
+                const int ch = a.codes[(size_t)op.y * a.Spad + sc];
+                const double2 *tp = reinterpret_cast<const double2 *>(
+                    a.tip + ((((size_t)c * (a.ntips + 1) + t) * a.nchar + ch) * 4 + g) * R);
+                if (code == OP_TIP_SET) {
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) { const double2 v = tp[r >> 1]; x[r] = v.x; x[r + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) { const double2 v = tp[r >> 1]; x[r] *= v.x; x[r + 1] *= v.y; }
+                }
+            } else if (code == OP_PUSH) {
+                double *sp = a.slots + (size_t)op.y * R * a.slot_stride + lin;
+#pragma unroll
+                for (int r = 0; r < R; r++) sp[(size_t)r * a.slot_stride] = x[r];
+            } else if (code == OP_POPMUL) {
+                const double *sp = a.slots + (size_t)op.y * R * a.slot_stride + lin;
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] *= sp[(size_t)r * a.slot_stride];
+            } else if (code == OP_SCALE) {
+                double m = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; r++) m = fmax(m, x[r]);
+                m = fmax(m, __shfl_xor(m, 16, 64));
+                m = fmax(m, __shfl_xor(m, 32, 64));
+                const int e = frexp_exp(m);
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = ldexp(x[r], -e);
+                esc += e;
+            }
+        }
+        /* root expectation: weights in the same distributed layout, then across the 4 lanes of the site */
+        double lh = 0.0;
+        const double *rw = a.root_wd + g * R;
+#pragma unroll
+        for (int r = 0; r < R; r++) lh = fma(rw[r], x[r], lh);
+        lh += __shfl_xor(lh, 16, 64);
+        lh += __shfl_xor(lh, 32, 64);
+        const double term = a.cat_prior[c] * lh;
+        if (term != 0.0) {
+            if (!have) { sum = term; Eexp = esc; have = true; }
+            else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
+            else sum += ldexp(term, esc - Eexp);
+        }
+    }
+    const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
+    dd v = dd_make(0.0, 0.0);
+    if (valid && g == 0) {
+        if (a.site_ll) a.site_ll[site] = ll;
+        v = a.w ? dd_two_prod(a.w[site], ll) : dd_make(ll, 0.0);
+    }
+    if (a.partial) {
+        dd r = dd_block_sum(v);
+        if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+/* A fragments: frag[((c*nops + pc)*T + t)*kk4 + q][l] = P[c][edge(pc)][16t + (l&15)][4q + (l>>4)] */
+__global__ void k_build_frag(int k, int T, int kk4, int E, int nops, const int *__restrict__ op_edge,
+                             const double *__restrict__ P, double *__restrict__ frag)
+{
+    const int pc = blockIdx.x, c = blockIdx.y;
+    const int e = op_edge[pc];
+    double *dst = frag + ((size_t)c * nops + pc) * T * kk4 * 64;
+    const int n = T * kk4 * 64;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const int l = idx & 63, tq = idx >> 6;
+        const int t = tq / kk4, q = tq - t * kk4;
+        const int i = 16 * t + (l & 15), j = 4 * q + (l >> 4);
+        double v = 0.0;
+        if (e >= 0 && i < k && j < k) v = P[((size_t)c * E + e) * k * k + (size_t)i * k + j];
+        dst[idx] = v;
+    }
+}
+
+/* distributed tip tables: tip[(((c*(ntips+1) + t)*nchar + code)*4 + g)*R + r] = (P_e defs[code])[g + 4r]
+ * (dd accumulation; exact for constant definition rows; slot ntips holds defs[code] itself) */
+__global__ void k_build_tip_dist(int k, int R, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
+                                 const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][K] */, int Kpad,
+                                 double *__restrict__ tip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int e = tip_edge[t];
+    const int n = nchar * 4 * R;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const int r = idx % R, gq = idx / R;
+        const int g = gq & 3, code = gq >> 2;
+        const int i = g + 4 * r;
+        const double *d = defs + (size_t)code * Kpad;
+        double out = 0.0;
+        if (i < k) {
+            if (e < 0) out = d[i];
+            else {
+                bool constant = true;
+                for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
+                if (constant) out = d[0];
+                else {
+                    const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                    dd acc = dd_make(0.0, 0.0);
+                    for (int j = 0; j < k; j++) acc = dd_add(acc, dd_mul_d(Pm[j], d[j]));
+                    out = acc.hi;
+                }
+            }
+        }
+        tip[(((size_t)c * (ntips + 1) + t) * nchar + code) * 4 * R + (size_t)g * R + r] = out;
+    }
+}
+
+#endif

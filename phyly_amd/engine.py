@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libarbplf_amd.so")
 HOST, DEVICE = 0, 1
 ROOT_NONE, ROOT_CUSTOM, ROOT_UNIFORM, ROOT_EQUILIBRIUM = 1, 2, 3, 4
 INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS = range(5)
-OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM = 0, 1, 2, 3
+OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA = 0, 1, 2, 3, 4
 
 _lib = None
 
