@@ -72,6 +72,7 @@ struct plk_engine {
     dd *d_Pdd = nullptr;                 /* [C][E][k*k] unrounded */
     double *d_P = nullptr, *d_dP = nullptr; /* [C][E][k][k] rounded; dP = r_c Qn P */
     dd *d_scratch = nullptr;
+    size_t pdd_cap = 0, p_cap = 0, dp_cap = 0, scratch_cap = 0;
     bool model_dirty = true;
 
     /* patterns */
@@ -187,7 +188,7 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 
 #define EXPM_TERMS 28
 
-__global__ void k_expm_dd(int k, int E, const double *__restrict__ Qn /* [2][k*k]: hi then lo */,
+__global__ __launch_bounds__(1024) void k_expm_dd(int k, int E, const double *__restrict__ Qn /* [2][k*k]: hi then lo */,
                           const double *__restrict__ edge_rates,
                           const double *__restrict__ cat_rates,
                           dd *__restrict__ Pdd, double *__restrict__ P, double *__restrict__ dP,
@@ -388,6 +389,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
 #include "plk_mfma.h"
+#include "plk_mfma_updown.h"
 
 /* ====================================================================== */
 /* K2+K3 generic: any k <= K, stack slots in HBM                           */
@@ -946,13 +948,14 @@ static int run_expm(plk_engine *h)
     const int k = h->k, C = h->C, E = h->E;
     const size_t kk = (size_t)k * k, n = (size_t)C * E * kk;
     int rc;
-    if ((rc = dev_alloc(h, &h->d_Pdd, n))) return rc;
-    if ((rc = dev_alloc(h, &h->d_P, n))) return rc;
-    if ((rc = dev_alloc(h, &h->d_dP, n))) return rc;
+    if ((rc = dev_reserve(h, &h->d_Pdd, &h->pdd_cap, n))) return rc;
+    if ((rc = dev_reserve(h, &h->d_P, &h->p_cap, n))) return rc;
+    if ((rc = dev_reserve(h, &h->d_dP, &h->dp_cap, n))) return rc;
     const size_t lds_bytes = 4 * kk * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds) { if ((rc = dev_alloc(h, &h->d_scratch, (size_t)C * E * 4 * kk))) return rc; }
-    const int threads = kk >= 256 ? 256 : 64;
+    if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * 4 * kk))) return rc; }
+    /* one thread per few matrix entries: the dd matrix products are the whole cost for k = 61 */
+    const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
     hipLaunchKernelGGL(k_expm_dd, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
                        h->d_scratch, use_lds);
@@ -1498,6 +1501,129 @@ static int wsum_rows(plk_engine *h, int rows, long n, const double *X, const dou
     return PLK_OK;
 }
 
+template <int T>
+static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, unsigned grid, size_t lds, bool deriv, bool marg)
+{
+    hipLaunchKernelGGL(k_down_store_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    if (deriv && marg) hipLaunchKernelGGL((k_up_mfma<T, true, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    else if (deriv) hipLaunchKernelGGL((k_up_mfma<T, true, false>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    else hipLaunchKernelGGL((k_up_mfma<T, false, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+}
+
+/* deriv / marginal for 9 <= k <= 64 with compact codes: matrix-core kernels (plk_mfma_updown.h) */
+static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
+                           double *site_out, double *sums_out)
+{
+    int rc;
+    const int N = h->N, E = h->E, k = h->k, C = h->C;
+    const int T = (k + 15) / 16, R = 4 * T, kk4 = (k + 3) / 4;
+    const long S = h->S;
+    if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
+    const int ntips = (int)h->tip_edge.size();
+    std::vector<int> edge_tip(E, -1), edge_int(E, -1), node_int(N, -1);
+    for (int t = 0; t < ntips; t++) edge_tip[h->tip_edge[t]] = t;
+    int nie = 0, nin = 0;
+    for (int e = 0; e < E; e++) if (edge_tip[e] < 0) edge_int[e] = nie++;
+    for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a]) node_int[a] = nin++;
+    std::vector<int> te = h->tip_edge;
+    te.push_back(-1);
+    std::vector<double> rwd((size_t)4 * R, 0.0);
+    for (int i = 0; i < k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
+
+    int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
+    char *d_has = nullptr;
+    double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
+    auto cleanup = [&]() {
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
+        for (void *p : ps) if (p) (void)hipFree(p);
+    };
+    const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
+    if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)E)) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)E)) ||
+        (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
+        (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) ||
+        (rc = dev_alloc(h, &d_fP, nfr)) || (rc = dev_alloc(h, &d_fPT, nfr)) || (rc = dev_alloc(h, &d_fD, nfr)) ||
+        (rc = dev_alloc(h, &d_tipd, ntab)) || (rc = dev_alloc(h, &d_dtip, ntab))) { cleanup(); return rc; }
+    if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
+    if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
+    if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+    if ((rc = dev_upload(h, &d_has, h->node_has_data.data(), (size_t)N))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_P, d_fP);
+    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 1, h->d_P, d_fPT);
+    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_dP, d_fD);
+    hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                       k, R, E, ntips, h->nchar, d_te, h->d_Pdd, h->d_defs, h->K, d_tipd);
+    hipLaunchKernelGGL(k_build_dtip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                       k, R, E, ntips, h->nchar, d_te, h->d_dP, h->d_defs, h->K, d_dtip);
+    if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
+
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
+    budget += h->work_cap * sizeof(double);
+    long chunk = (long)std::min<size_t>((size_t)((S + MF_SITES - 1) / MF_SITES * MF_SITES), budget / per_site);
+    if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
+    chunk = chunk / MF_SITES * MF_SITES;
+    if (chunk < MF_SITES) { cleanup(); h->err = "plk_deriv/plk_marginal: not enough device memory"; return PLK_E_NOMEM; }
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
+
+    std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
+    std::vector<double> stage;
+    for (long s0 = 0; s0 < S; s0 += chunk) {
+        const long n = std::min(chunk, S - s0);
+        const unsigned grid = (unsigned)((n + MF_SITES - 1) / MF_SITES);
+        MUpArgs a;
+        a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
+        a.N = N; a.E = E; a.k = k; a.kk4 = kk4; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
+        a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
+        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni;
+        a.fragP = d_fP; a.fragPT = d_fPT; a.fragD = d_fD; a.tip = d_tipd; a.dtip = d_dtip;
+        a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = d_rwd; a.edge_mask = d_emask; a.node_mask = d_nmask;
+        a.stride = (long)grid * MF_SITES * 4;
+        double *p = h->d_work;
+        a.EV = p; p += (size_t)nie * C * R * a.stride;
+        a.LN = p; p += (size_t)nin * C * R * a.stride;
+        a.FN = p; p += (size_t)nin * C * R * a.stride;
+        a.LH = p; p += n;
+        a.DV = p; if (deriv) p += (size_t)E * n;
+        a.MV = p; if (marg) p += (size_t)N * k * n;
+        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
+        const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
+        if (T == 1) launch_updown_mfma<1>(h, a, grid, lds, deriv, marg);
+        else if (T == 2) launch_updown_mfma<2>(h, a, grid, lds, deriv, marg);
+        else if (T == 3) launch_updown_mfma<3>(h, a, grid, lds, deriv, marg);
+        else launch_updown_mfma<4>(h, a, grid, lds, deriv, marg);
+        if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
+        if (sums_out) {
+            const double *w = h->d_w ? h->d_w + s0 : nullptr;
+            if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
+            if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
+        }
+        if (site_out) {
+            const size_t rows = deriv ? (size_t)E : (size_t)N * k;
+            stage.resize(rows * (size_t)n);
+            hipError_t e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+            for (size_t r = 0; r < rows; r++)
+                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
+        }
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) { h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+    if (sums_out) {
+        const std::vector<long double> &src = deriv ? dsum : msum;
+        for (size_t r = 0; r < src.size(); r++) {
+            const double hi = (double)src[r];
+            sums_out[2 * r] = hi;
+            sums_out[2 * r + 1] = (double)(src[r] - (long double)hi);
+        }
+    }
+    return PLK_OK;
+}
+
 static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
                       double *site_out, double *sums_out)
 {
@@ -1505,6 +1631,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out);
     const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
     const long S = h->S;
     /* padded edge-indexed streams */

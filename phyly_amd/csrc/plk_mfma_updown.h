@@ -1,0 +1,337 @@
+/*
+ * plk_mfma_updown.h -- down pass with stored vectors and BFS-order up pass (edge
+ * derivatives, marginals) for 9 <= k <= 64 on the fp64 matrix cores.  Included by
+ * plk_engine.hip after plk_mfma.h; same distributed layout (a site's vector spread over
+ * the 4 lanes {s, s+16, s+32, s+48}, lane group g holding states g, g+4, ...).
+ *
+ * Replaces for large state spaces (same formulas as k_down_store / k_up):
+ *   src/evaluate_site_lhood.c:7-63 (with edge vectors), src/evaluate_site_forward.c:32-105,
+ *   src/arbplfderiv.c:112-207,:312-342, src/evaluate_site_marginal.c:7-21, src/arbplfmarginal.c:206-234.
+ *
+ * Leaf edges never touch the matrix cores: their edge vectors P_e B_b and derivative
+ * vectors dP_e B_b are gathered from per-edge tables indexed by the pattern code
+ * (built in double-double).  Internal edges stage the A fragments of P_e, P_e^T or dP_e
+ * through LDS once per workgroup.
+ */
+#ifndef PLK_MFMA_UPDOWN_H
+#define PLK_MFMA_UPDOWN_H
+
+struct MUpArgs {
+    long S, Spad, s0, n;          /* chunk [s0, s0+n) of the pattern extent */
+    int N, E, k, kk4, C, nchar, ntips, root_mode;
+    const int *indptr, *indices, *preorder;
+    const char *node_has_data;
+    const int *edge_tip;          /* E: tip slot of a leaf edge, -1 for internal edges */
+    const int *edge_int;          /* E: index among internal edges, -1 for leaf edges */
+    const int *node_int;          /* N: index among internal nodes, -1 for leaves */
+    const double *fragP, *fragPT, *fragD;   /* [C][E][T][kk4][64] */
+    const double *tip;            /* [C][ntips+1][nchar][4][R]: P_e defs, last slot raw defs */
+    const double *dtip;           /* [C][ntips+1][nchar][4][R]: dP_e defs */
+    const uint8_t *codes;
+    const double *cat_prior, *root_wd;
+    const int *edge_mask, *node_mask;
+    double *EV, *LN, *FN;         /* [(ent*C + c)*R + r][stride] planes, lane-linear */
+    long stride;
+    double *LH;                   /* [n] */
+    double *DV;                   /* [E][n] */
+    double *MV;                   /* [N][k][n] */
+};
+
+template <int R>
+__device__ static inline void mf_gather(const double *tab, int nchar, int slot, int ch, int g, double (&out)[R])
+{
+    const double2 *tp = reinterpret_cast<const double2 *>(tab + (((size_t)slot * nchar + ch) * 4 + g) * R);
+#pragma unroll
+    for (int r = 0; r < R; r += 2) { const double2 v = tp[r >> 1]; out[r] = v.x; out[r + 1] = v.y; }
+}
+
+template <int R>
+__device__ static inline void mf_load(const double *base, long stride, long lin, double (&out)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) out[r] = base[(size_t)r * stride + lin];
+}
+
+template <int R>
+__device__ static inline void mf_store(double *base, long stride, long lin, const double (&v)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) base[(size_t)r * stride + lin] = v[r];
+}
+
+/* all k states of the site equal? (the reference's exact constant-column test, src/arb_mat_extras.c:36-51) */
+template <int R>
+__device__ static inline bool mf_is_const(const double (&x)[R], int g, int k, double &x0)
+{
+    double lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (g + 4 * r < k) { lo = fmin(lo, x[r]); hi = fmax(hi, x[r]); }
+    lo = fmin(lo, __shfl_xor(lo, 16, 64)); lo = fmin(lo, __shfl_xor(lo, 32, 64));
+    hi = fmax(hi, __shfl_xor(hi, 16, 64)); hi = fmax(hi, __shfl_xor(hi, 32, 64));
+    x0 = lo;
+    return lo == hi;
+}
+
+/* y = M x with M given as A fragments already staged in LDS */
+template <int T>
+__device__ static inline void mf_matvec(const double *lds_frag, int kk4, int lane, const double (&x)[4 * T], double (&y)[4 * T])
+{
+    plk_d4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = (plk_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4 * T; q++) {
+        if (q < kk4) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_frag[(t * kk4 + q) * 64 + lane], x[q], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        y[4 * t + 0] = acc[t][0]; y[4 * t + 1] = acc[t][1]; y[4 * t + 2] = acc[t][2]; y[4 * t + 3] = acc[t][3];
+    }
+}
+
+__device__ static inline void mf_stage(double *lds_frag, const double *src, int nfrag, int tid)
+{
+    __syncthreads();
+    for (int i = tid; i < nfrag / 2; i += MF_BLOCK)
+        reinterpret_cast<double2 *>(lds_frag)[i] = reinterpret_cast<const double2 *>(src)[i];
+    __syncthreads();
+}
+
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
+{
+    extern __shared__ double lds_frag[];
+    constexpr int R = 4 * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const long sl = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
+    const bool valid = sl < a.n;
+    const long sg = a.s0 + (valid ? sl : a.n - 1);
+    const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;
+    const int nfrag = T * a.kk4 * 64;
+    const int NT = a.ntips + 1;
+    double lh_total = 0.0;
+    for (int c = 0; c < a.C; c++) {
+        const double *tipc = a.tip + (size_t)c * NT * a.nchar * 4 * R;
+        double lh_c = 0.0;
+        for (int u = a.N - 1; u >= 0; u--) {
+            const int nd = a.preorder[u];
+            const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+            if (start == stop) continue;
+            double acc[R];
+            if (a.node_has_data[nd]) mf_gather<R>(tipc, a.nchar, a.ntips, a.codes[(size_t)nd * a.Spad + sg], g, acc);
+            else {
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = (g + 4 * r < a.k) ? 1.0 : 0.0;
+            }
+            for (int idx = start; idx < stop; idx++) {
+                const int b = a.indices[idx];
+                double m[R];
+                if (a.edge_tip[idx] >= 0) {
+                    mf_gather<R>(tipc, a.nchar, a.edge_tip[idx], a.codes[(size_t)b * a.Spad + sg], g, m);
+                } else {
+                    double x[R];
+                    mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                    mf_stage(lds_frag, a.fragP + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
+                    mf_matvec<T>(lds_frag, a.kk4, lane, x, m);
+                    double x0;
+                    if (mf_is_const<R>(x, g, a.k, x0)) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) m[r] = (g + 4 * r < a.k) ? x0 : 0.0;
+                    }
+                    mf_store<R>(a.EV + ((size_t)a.edge_int[idx] * a.C + c) * R * a.stride, a.stride, lin, m);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] *= m[r];
+            }
+            mf_store<R>(a.LN + ((size_t)a.node_int[nd] * a.C + c) * R * a.stride, a.stride, lin, acc);
+            if (u == 0) {
+                const double *rw = a.root_wd + g * R;
+#pragma unroll
+                for (int r = 0; r < R; r++) lh_c = fma(rw[r], acc[r], lh_c);
+                lh_c += __shfl_xor(lh_c, 16, 64);
+                lh_c += __shfl_xor(lh_c, 32, 64);
+            }
+        }
+        lh_total = fma(a.cat_prior[c], lh_c, lh_total);
+    }
+    if (valid && g == 0) a.LH[sl] = lh_total;
+}
+
+template <int T, bool DERIV, bool MARG>
+__global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
+{
+    extern __shared__ double lds_frag[];
+    constexpr int R = 4 * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const long sl = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;
+    const int nfrag = T * a.kk4 * 64;
+    const int NT = a.ntips + 1;
+    const size_t tabc = (size_t)NT * a.nchar * 4 * R;
+    const size_t n = (size_t)a.n;
+    const double inv = 1.0 / a.LH[slc];
+    const int root = a.preorder[0];
+    const double *rw = a.root_wd + g * R;
+
+    {   /* root: forward vector = root weights; its marginal */
+        double macc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) macc[r] = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            double f[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) f[r] = rw[r];
+            mf_store<R>(a.FN + ((size_t)a.node_int[root] * a.C + c) * R * a.stride, a.stride, lin, f);
+            if (MARG) {
+                double l[R];
+                mf_load<R>(a.LN + ((size_t)a.node_int[root] * a.C + c) * R * a.stride, a.stride, lin, l);
+#pragma unroll
+                for (int r = 0; r < R; r++) macc[r] = fma(a.cat_prior[c] * f[r], l[r], macc[r]);
+            }
+        }
+        if (MARG && (!a.node_mask || a.node_mask[root])) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (g + 4 * r < a.k && valid) a.MV[((size_t)root * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
+        }
+    }
+
+    for (int u = 0; u < a.N; u++) {
+        const int nd = a.preorder[u];
+        const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+        if (start == stop) continue;
+        const bool has = a.node_has_data[nd];
+        const int chn = has ? a.codes[(size_t)nd * a.Spad + sg] : 0;
+        for (int idx = start; idx < stop; idx++) {
+            const int b = a.indices[idx];
+            const bool b_leaf = a.edge_tip[idx] >= 0;
+            const bool want_d = DERIV && (!a.edge_mask || a.edge_mask[idx]);
+            const bool want_m = MARG && (!a.node_mask || a.node_mask[b]);
+            const bool want_f = !b_leaf || want_m;
+            if (!want_d && !want_f) continue;
+            const int chb = b_leaf ? a.codes[(size_t)b * a.Spad + sg] : 0;
+            double dsum = 0.0;
+            double macc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) macc[r] = 0.0;
+            for (int c = 0; c < a.C; c++) {
+                const double *tipc = a.tip + (size_t)c * tabc;
+                double fe[R];
+                mf_load<R>(a.FN + ((size_t)a.node_int[nd] * a.C + c) * R * a.stride, a.stride, lin, fe);
+                if (has) {
+                    double bn[R];
+                    mf_gather<R>(tipc, a.nchar, a.ntips, chn, g, bn);
+#pragma unroll
+                    for (int r = 0; r < R; r++) fe[r] *= bn[r];
+                }
+                for (int idx2 = start; idx2 < stop; idx2++) {
+                    if (idx2 == idx) continue;
+                    double ev[R];
+                    if (a.edge_tip[idx2] >= 0)
+                        mf_gather<R>(tipc, a.nchar, a.edge_tip[idx2], a.codes[(size_t)a.indices[idx2] * a.Spad + sg], g, ev);
+                    else
+                        mf_load<R>(a.EV + ((size_t)a.edge_int[idx2] * a.C + c) * R * a.stride, a.stride, lin, ev);
+#pragma unroll
+                    for (int r = 0; r < R; r++) fe[r] *= ev[r];
+                }
+                const double prior = a.cat_prior[c];
+                if (want_d) {
+                    double y[R];
+                    if (b_leaf) {
+                        mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, a.edge_tip[idx], chb, g, y);
+                    } else {
+                        double x[R], x0;
+                        mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                        mf_stage(lds_frag, a.fragD + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
+                        mf_matvec<T>(lds_frag, a.kk4, lane, x, y);
+                        if (mf_is_const<R>(x, g, a.k, x0)) {
+#pragma unroll
+                            for (int r = 0; r < R; r++) y[r] = 0.0;
+                        }
+                    }
+                    double d = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) d = fma(fe[r], y[r], d);
+                    d += __shfl_xor(d, 16, 64);
+                    d += __shfl_xor(d, 32, 64);
+                    dsum = fma(prior, d, dsum);
+                }
+                if (want_f) {
+                    double fb[R];
+                    mf_stage(lds_frag, a.fragPT + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
+                    mf_matvec<T>(lds_frag, a.kk4, lane, fe, fb);
+                    if (!b_leaf) mf_store<R>(a.FN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, fb);
+                    if (want_m) {
+                        double lb[R];
+                        if (b_leaf) mf_gather<R>(tipc, a.nchar, a.ntips, chb, g, lb);
+                        else mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, lb);
+#pragma unroll
+                        for (int r = 0; r < R; r++) macc[r] = fma(prior * fb[r], lb[r], macc[r]);
+                    }
+                }
+            }
+            if (want_d && valid && g == 0) a.DV[(size_t)idx * n + sl] = dsum * inv;
+            if (want_m) {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (g + 4 * r < a.k && valid) a.MV[((size_t)b * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
+            }
+        }
+    }
+}
+
+/* A fragments of an edge-indexed matrix set M[C*E][k][k]: transpose = 0: of M, 1: of M^T */
+__global__ void k_build_frag_edges(int k, int T, int kk4, int transpose, const double *__restrict__ M, double *__restrict__ frag)
+{
+    const size_t ce = blockIdx.x;
+    const double *src = M + ce * k * k;
+    double *dst = frag + ce * T * kk4 * 64;
+    const int nn = T * kk4 * 64;
+    for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
+        const int l = idx & 63, tq = idx >> 6;
+        const int t = tq / kk4, q = tq - t * kk4;
+        const int i = 16 * t + (l & 15), j = 4 * q + (l >> 4);
+        double v = 0.0;
+        if (i < k && j < k) v = transpose ? src[(size_t)j * k + i] : src[(size_t)i * k + j];
+        dst[idx] = v;
+    }
+}
+
+/* derivative tip table: dtip[...][g][r] = (dP_e defs[code])[g + 4r], zero for constant rows
+ * (rows of dP sum to zero; the reference's exact shortcut, src/util.c:338-345) */
+__global__ void k_build_dtip_dist(int k, int R, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
+                                  const double *__restrict__ dP, const double *__restrict__ defs, int Kpad,
+                                  double *__restrict__ dtip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int e = tip_edge[t];
+    const int nn = nchar * 4 * R;
+    for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
+        const int r = idx % R, gq = idx / R;
+        const int g = gq & 3, code = gq >> 2;
+        const int i = g + 4 * r;
+        const double *d = defs + (size_t)code * Kpad;
+        double out = 0.0;
+        if (i < k && e >= 0) {
+            bool constant = true;
+            for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
+            if (!constant) {
+                const double *row = dP + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                dd acc = dd_make(0.0, 0.0);
+                for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
+                out = acc.hi;
+            }
+        }
+        dtip[(((size_t)c * (ntips + 1) + t) * nchar + code) * 4 * R + (size_t)g * R + r] = out;
+    }
+}
+
+#endif
