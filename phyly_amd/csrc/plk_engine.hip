@@ -444,7 +444,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_ll_generic(GenArgs a)
         int esc = 0;
         const double *PSc = a.PS + (size_t)c * a.nops * K * K;
         for (int pc = 0; pc < a.nops; pc++) {
-            const int2 op = a.ops[pc];
+            int2 op;
+            op.x = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc];
+            op.y = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc + 1];
             const int code = op.x & 0xff;
             if (code == OP_MATVEC || code == OP_TIP_SET || code == OP_TIP_MUL) {
                 if (code == OP_MATVEC) {
@@ -531,7 +533,7 @@ struct UpArgs {
     long s0, n;          /* chunk [s0, s0+n) */
     int N, E, k, C, nchar, pat_mode, root_mode;
     const int *indptr, *indices, *preorder;
-    const char *node_has_data;  /* N */
+    const int *node_has_data;  /* N */
     const double *PT;    /* [C][E][K*K] transposed P:  PT[j*K+i] = P[i][j]  */
     const double *PN;    /* [C][E][K*K] plain P:       PN[i*K+j] = P[i][j]  */
     const double *DT;    /* [C][E][K*K] transposed dP: DT[j*K+i] = dP[i][j] */
@@ -615,18 +617,18 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
     for (int c = 0; c < a.C; c++) {
         double lh_c = 0.0;
         for (int u = a.N - 1; u >= 0; u--) {
-            const int nd = a.preorder[u];
-            const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+            const int nd = as_uniform(a.preorder)[u];
+            const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
             if (start == stop) continue;
             double acc[K];
-            if (a.node_has_data[nd]) up_load_obs_reg<K>(a, nd, sg, acc);
+            if (as_uniform(a.node_has_data)[nd]) up_load_obs_reg<K>(a, nd, sg, acc);
             else {
 #pragma unroll
                 for (int i = 0; i < K; i++) acc[i] = 1.0;
             }
             for (int idx = start; idx < stop; idx++) {
-                const int b = a.indices[idx];
-                if (a.indptr[b] == a.indptr[b + 1]) up_stage_obs<K>(a, b, sg, tid, xs);
+                const int b = as_uniform(a.indices)[idx];
+                if (as_uniform(a.indptr)[b] == as_uniform(a.indptr)[b + 1]) up_stage_obs<K>(a, b, sg, tid, xs);
                 else {
                     const double *lb = a.LN + ((size_t)b * a.C + c) * a.k * n + slc;
                     for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
@@ -652,11 +654,11 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
                     if (a.root_mode == PLK_ROOT_UNIFORM) lh_c /= (double)a.k;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < K; i++) lh_c = fma(a.root_w[i], acc[i], lh_c);
+                    for (int i = 0; i < K; i++) lh_c = fma(as_uniform(a.root_w)[i], acc[i], lh_c);
                 }
             }
         }
-        lh_total = fma(a.cat_prior[c], lh_c, lh_total);
+        lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total);
     }
     if (valid) a.LH[sl] = lh_total;
 }
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
     const long sg = a.s0 + slc;
     const size_t n = (size_t)a.n;
     const double inv = 1.0 / a.LH[slc];
-    const int root = a.preorder[0];
+    const int root = as_uniform(a.preorder)[0];
 
     /* root: forward vector = root prior weights; its marginal */
     {
@@ -693,12 +695,12 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
 #pragma unroll
             for (int i = 0; i < K; i++) {
                 if (i < a.k) {
-                    if (valid) fr[(size_t)i * n] = a.root_w[i];
-                    if (MARG) macc[i] = fma(a.cat_prior[c] * a.root_w[i], lr[(size_t)i * n], macc[i]);
+                    if (valid) fr[(size_t)i * n] = as_uniform(a.root_w)[i];
+                    if (MARG) macc[i] = fma(as_uniform(a.cat_prior)[c] * as_uniform(a.root_w)[i], lr[(size_t)i * n], macc[i]);
                 }
             }
         }
-        if (MARG && (!a.node_mask || a.node_mask[root])) {
+        if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) {
             double *mv = a.MV + (size_t)root * a.k * n + slc;
 #pragma unroll
             for (int i = 0; i < K; i++)
@@ -707,17 +709,17 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
     }
 
     for (int u = 0; u < a.N; u++) {
-        const int nd = a.preorder[u];
-        const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+        const int nd = as_uniform(a.preorder)[u];
+        const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
         if (start == stop) continue;
         double bnd[K];
-        const bool has = a.node_has_data[nd];
+        const bool has = as_uniform(a.node_has_data)[nd];
         if (has) up_load_obs_reg<K>(a, nd, sg, bnd);
         for (int idx = start; idx < stop; idx++) {
-            const int b = a.indices[idx];
-            const bool b_leaf = a.indptr[b] == a.indptr[b + 1];
-            const bool want_d = DERIV && (!a.edge_mask || a.edge_mask[idx]);
-            const bool want_m = MARG && (!a.node_mask || a.node_mask[b]);
+            const int b = as_uniform(a.indices)[idx];
+            const bool b_leaf = as_uniform(a.indptr)[b] == as_uniform(a.indptr)[b + 1];
+            const bool want_d = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[idx]);
+            const bool want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[b]);
             const bool want_f = !b_leaf || want_m;
             if (!want_d && !want_f) continue;
             double dsum = 0.0;
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                     for (int i = 0; i < K; i++)
                         if (i < a.k) fe[i] *= ev[(size_t)i * n];
                 }
-                const double prior = a.cat_prior[c];
+                const double prior = as_uniform(a.cat_prior)[c];
                 if (want_d) {
                     /* y = dP_e * L_b ; d = fe . y */
                     if (b_leaf) up_stage_obs<K>(a, b, sg, tid, xs);
@@ -1531,7 +1533,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     for (int i = 0; i < k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    char *d_has = nullptr;
+    int *d_has = nullptr;
     double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
     auto cleanup = [&]() {
         void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
@@ -1546,7 +1548,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
-    if ((rc = dev_upload(h, &d_has, h->node_has_data.data(), (size_t)N))) { cleanup(); return rc; }
+    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_P, d_fP);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 1, h->d_P, d_fPT);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_dP, d_fD);
@@ -1637,7 +1639,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     /* padded edge-indexed streams */
     double *d_PT = nullptr, *d_PN = nullptr, *d_DT = nullptr;
     int *d_emask = nullptr, *d_nmask = nullptr;
-    char *d_has = nullptr;
+    int *d_has = nullptr;
     const size_t strm = (size_t)C * E * K * K;
     auto cleanup = [&]() {
         if (d_PT) (void)hipFree(d_PT);
@@ -1655,7 +1657,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
-    if ((rc = dev_upload(h, &d_has, h->node_has_data.data(), (size_t)N))) { cleanup(); return rc; }
+    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
 
     /* chunk the site axis so that the stored vectors fit */
     const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
         for (int r = 0; r < R; r++) x[r] = 1.0;
         int esc = 0;
         for (int pc = 0; pc < a.nops; pc++) {
-            const int2 op = a.ops[pc];
+            int2 op;
+            op.x = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc];
+            op.y = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc + 1];
             const int code = op.x & 0xff;
             if (code == OP_MATVEC) {
                 /* stage the A fragments of this edge (same for all 4 waves) */
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
         for (int r = 0; r < R; r++) lh = fma(rw[r], x[r], lh);
         lh += __shfl_xor(lh, 16, 64);
         lh += __shfl_xor(lh, 32, 64);
-        const double term = a.cat_prior[c] * lh;
+        const double term = as_uniform(a.cat_prior)[c] * lh;
         if (term != 0.0) {
             if (!have) { sum = term; Eexp = esc; have = true; }
             else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }

@@ -20,7 +20,7 @@ struct MUpArgs {
     long S, Spad, s0, n;          /* chunk [s0, s0+n) of the pattern extent */
     int N, E, k, kk4, C, nchar, ntips, root_mode;
     const int *indptr, *indices, *preorder;
-    const char *node_has_data;
+    const int *node_has_data;
     const int *edge_tip;          /* E: tip slot of a leaf edge, -1 for internal edges */
     const int *edge_int;          /* E: index among internal edges, -1 for leaf edges */
     const int *node_int;          /* N: index among internal nodes, -1 for leaves */
@@ -119,23 +119,23 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
         const double *tipc = a.tip + (size_t)c * NT * a.nchar * 4 * R;
         double lh_c = 0.0;
         for (int u = a.N - 1; u >= 0; u--) {
-            const int nd = a.preorder[u];
-            const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+            const int nd = as_uniform(a.preorder)[u];
+            const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
             if (start == stop) continue;
             double acc[R];
-            if (a.node_has_data[nd]) mf_gather<R>(tipc, a.nchar, a.ntips, a.codes[(size_t)nd * a.Spad + sg], g, acc);
+            if (as_uniform(a.node_has_data)[nd]) mf_gather<R>(tipc, a.nchar, a.ntips, a.codes[(size_t)nd * a.Spad + sg], g, acc);
             else {
 #pragma unroll
                 for (int r = 0; r < R; r++) acc[r] = (g + 4 * r < a.k) ? 1.0 : 0.0;
             }
             for (int idx = start; idx < stop; idx++) {
-                const int b = a.indices[idx];
+                const int b = as_uniform(a.indices)[idx];
                 double m[R];
-                if (a.edge_tip[idx] >= 0) {
-                    mf_gather<R>(tipc, a.nchar, a.edge_tip[idx], a.codes[(size_t)b * a.Spad + sg], g, m);
+                if (as_uniform(a.edge_tip)[idx] >= 0) {
+                    mf_gather<R>(tipc, a.nchar, as_uniform(a.edge_tip)[idx], a.codes[(size_t)b * a.Spad + sg], g, m);
                 } else {
                     double x[R];
-                    mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                    mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, x);
                     mf_stage(lds_frag, a.fragP + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                     mf_matvec<T>(lds_frag, a.kk4, lane, x, m);
                     double x0;
@@ -143,12 +143,12 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
 #pragma unroll
                         for (int r = 0; r < R; r++) m[r] = (g + 4 * r < a.k) ? x0 : 0.0;
                     }
-                    mf_store<R>(a.EV + ((size_t)a.edge_int[idx] * a.C + c) * R * a.stride, a.stride, lin, m);
+                    mf_store<R>(a.EV + ((size_t)as_uniform(a.edge_int)[idx] * a.C + c) * R * a.stride, a.stride, lin, m);
                 }
 #pragma unroll
                 for (int r = 0; r < R; r++) acc[r] *= m[r];
             }
-            mf_store<R>(a.LN + ((size_t)a.node_int[nd] * a.C + c) * R * a.stride, a.stride, lin, acc);
+            mf_store<R>(a.LN + ((size_t)as_uniform(a.node_int)[nd] * a.C + c) * R * a.stride, a.stride, lin, acc);
             if (u == 0) {
                 const double *rw = a.root_wd + g * R;
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
                 lh_c += __shfl_xor(lh_c, 32, 64);
             }
         }
-        lh_total = fma(a.cat_prior[c], lh_c, lh_total);
+        lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total);
     }
     if (valid && g == 0) a.LH[sl] = lh_total;
 }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
     const size_t tabc = (size_t)NT * a.nchar * 4 * R;
     const size_t n = (size_t)a.n;
     const double inv = 1.0 / a.LH[slc];
-    const int root = a.preorder[0];
+    const int root = as_uniform(a.preorder)[0];
     const double *rw = a.root_wd + g * R;
 
     {   /* root: forward vector = root weights; its marginal */
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
             double f[R];
 #pragma unroll
             for (int r = 0; r < R; r++) f[r] = rw[r];
-            mf_store<R>(a.FN + ((size_t)a.node_int[root] * a.C + c) * R * a.stride, a.stride, lin, f);
+            mf_store<R>(a.FN + ((size_t)as_uniform(a.node_int)[root] * a.C + c) * R * a.stride, a.stride, lin, f);
             if (MARG) {
                 double l[R];
-                mf_load<R>(a.LN + ((size_t)a.node_int[root] * a.C + c) * R * a.stride, a.stride, lin, l);
+                mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[root] * a.C + c) * R * a.stride, a.stride, lin, l);
 #pragma unroll
-                for (int r = 0; r < R; r++) macc[r] = fma(a.cat_prior[c] * f[r], l[r], macc[r]);
+                for (int r = 0; r < R; r++) macc[r] = fma(as_uniform(a.cat_prior)[c] * f[r], l[r], macc[r]);
             }
         }
-        if (MARG && (!a.node_mask || a.node_mask[root])) {
+        if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) {
 #pragma unroll
             for (int r = 0; r < R; r++)
                 if (g + 4 * r < a.k && valid) a.MV[((size_t)root * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
@@ -205,16 +205,16 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
     }
 
     for (int u = 0; u < a.N; u++) {
-        const int nd = a.preorder[u];
-        const int start = a.indptr[nd], stop = a.indptr[nd + 1];
+        const int nd = as_uniform(a.preorder)[u];
+        const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
         if (start == stop) continue;
-        const bool has = a.node_has_data[nd];
+        const bool has = as_uniform(a.node_has_data)[nd];
         const int chn = has ? a.codes[(size_t)nd * a.Spad + sg] : 0;
         for (int idx = start; idx < stop; idx++) {
-            const int b = a.indices[idx];
-            const bool b_leaf = a.edge_tip[idx] >= 0;
-            const bool want_d = DERIV && (!a.edge_mask || a.edge_mask[idx]);
-            const bool want_m = MARG && (!a.node_mask || a.node_mask[b]);
+            const int b = as_uniform(a.indices)[idx];
+            const bool b_leaf = as_uniform(a.edge_tip)[idx] >= 0;
+            const bool want_d = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[idx]);
+            const bool want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[b]);
             const bool want_f = !b_leaf || want_m;
             if (!want_d && !want_f) continue;
             const int chb = b_leaf ? a.codes[(size_t)b * a.Spad + sg] : 0;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
             for (int c = 0; c < a.C; c++) {
                 const double *tipc = a.tip + (size_t)c * tabc;
                 double fe[R];
-                mf_load<R>(a.FN + ((size_t)a.node_int[nd] * a.C + c) * R * a.stride, a.stride, lin, fe);
+                mf_load<R>(a.FN + ((size_t)as_uniform(a.node_int)[nd] * a.C + c) * R * a.stride, a.stride, lin, fe);
                 if (has) {
                     double bn[R];
                     mf_gather<R>(tipc, a.nchar, a.ntips, chn, g, bn);
@@ -235,21 +235,21 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
                 for (int idx2 = start; idx2 < stop; idx2++) {
                     if (idx2 == idx) continue;
                     double ev[R];
-                    if (a.edge_tip[idx2] >= 0)
-                        mf_gather<R>(tipc, a.nchar, a.edge_tip[idx2], a.codes[(size_t)a.indices[idx2] * a.Spad + sg], g, ev);
+                    if (as_uniform(a.edge_tip)[idx2] >= 0)
+                        mf_gather<R>(tipc, a.nchar, as_uniform(a.edge_tip)[idx2], a.codes[(size_t)as_uniform(a.indices)[idx2] * a.Spad + sg], g, ev);
                     else
-                        mf_load<R>(a.EV + ((size_t)a.edge_int[idx2] * a.C + c) * R * a.stride, a.stride, lin, ev);
+                        mf_load<R>(a.EV + ((size_t)as_uniform(a.edge_int)[idx2] * a.C + c) * R * a.stride, a.stride, lin, ev);
 #pragma unroll
                     for (int r = 0; r < R; r++) fe[r] *= ev[r];
                 }
-                const double prior = a.cat_prior[c];
+                const double prior = as_uniform(a.cat_prior)[c];
                 if (want_d) {
                     double y[R];
                     if (b_leaf) {
-                        mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, a.edge_tip[idx], chb, g, y);
+                        mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, as_uniform(a.edge_tip)[idx], chb, g, y);
                     } else {
                         double x[R], x0;
-                        mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                        mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, x);
                         mf_stage(lds_frag, a.fragD + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                         mf_matvec<T>(lds_frag, a.kk4, lane, x, y);
                         if (mf_is_const<R>(x, g, a.k, x0)) {
@@ -268,11 +268,11 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
                     double fb[R];
                     mf_stage(lds_frag, a.fragPT + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                     mf_matvec<T>(lds_frag, a.kk4, lane, fe, fb);
-                    if (!b_leaf) mf_store<R>(a.FN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, fb);
+                    if (!b_leaf) mf_store<R>(a.FN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, fb);
                     if (want_m) {
                         double lb[R];
                         if (b_leaf) mf_gather<R>(tipc, a.nchar, a.ntips, chb, g, lb);
-                        else mf_load<R>(a.LN + ((size_t)a.node_int[b] * a.C + c) * R * a.stride, a.stride, lin, lb);
+                        else mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, lb);
 #pragma unroll
                         for (int r = 0; r < R; r++) macc[r] = fma(prior * fb[r], lb[r], macc[r]);
                     }
