@@ -153,21 +153,22 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        if kernel_kind == 1:
-            # fused register-stack traversal: partial vectors never reach HBM, so the
-            # north-star HBM model (A_ll bytes/site) does not bound it; fp64 FMA does.
+        kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma"}.get(kernel_kind, "?")
+        hbm_model = dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=hbm_equiv / HBM_PEAK,
+                         note="A_ll=%d B/site of the HBM-resident-partials design (SURVEY.md 8d)" % alg["A_ll"])
+        # which roof binds the kernel that ran: the fused and the matrix-core kernels keep the
+        # partial vectors out of HBM (compulsory traffic N+8 B/site), so fp64 arithmetic binds them;
+        # the generic vector kernel streams its stack slots through HBM.
+        fp64_bound = kernel_kind in (1, 3) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
+        if fp64_bound:
             roofline = dict(bound="mfma", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
-                            frac=flops / FP64_PEAK, traffic=traffic,
-                            kernel="k_ll_fused4", kernel_ms=kern_s * 1e3,
-                            note="fp64 vector FMA (fp64 MFMA dense peak is the same 78.6 TFLOP/s); "
-                                 "algorithmic flops W_ll=%d/site" % alg["W_ll"],
-                            hbm_model_equiv=dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                                                 frac=hbm_equiv / HBM_PEAK,
-                                                 note="A_ll=%d B/site of the HBM-resident-partials design" % alg["A_ll"]))
+                            frac=flops / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
+                            note="fp64 FMA peak (vector = fp64 MFMA dense peak = 78.6 TFLOP/s on MI355X); "
+                                 "achieved = algorithmic flops W_ll=%d/site x sites / kernel time" % alg["W_ll"],
+                            hbm_model_equiv=hbm_model)
         else:
             roofline = dict(bound="hbm", achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                            frac=hbm_equiv / HBM_PEAK, traffic=traffic,
-                            kernel="k_ll_generic", kernel_ms=kern_s * 1e3,
+                            frac=hbm_equiv / HBM_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
                             note="A_ll=%d B/site" % alg["A_ll"])
         out = {
             "metric": "sites/sec (arbplf-ll)", "value": value, "unit": "sites/s",
@@ -181,7 +182,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_ll = cpu_baseline(wl, min(4 * S, 40_000_000), args.cpu_seconds)
+            cb, cpu_ll = cpu_baseline(wl, min(2 * S, 20_000_000), args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
