@@ -628,17 +628,19 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
             }
             for (int idx = start; idx < stop; idx++) {
                 const int b = as_uniform(a.indices)[idx];
-                if (as_uniform(a.indptr)[b] == as_uniform(a.indptr)[b + 1]) up_stage_obs<K>(a, b, sg, tid, xs);
+                const bool b_leaf = as_uniform(a.indptr)[b] == as_uniform(a.indptr)[b + 1];
+                if (b_leaf) up_stage_obs<K>(a, b, sg, tid, xs);
                 else {
                     const double *lb = a.LN + ((size_t)b * a.C + c) * a.k * n + slc;
                     for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
                 }
                 double m[K];
                 up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, m);
+                /* leaf-edge vectors are not stored: the up pass recomputes them (k^2 flops vs 2k doubles of HBM) */
                 double *ev = a.EV + ((size_t)idx * a.C + c) * a.k * n + slc;
 #pragma unroll
                 for (int i = 0; i < K; i++) {
-                    if (i < a.k && valid) ev[(size_t)i * n] = m[i];
+                    if (!b_leaf && i < a.k && valid) ev[(size_t)i * n] = m[i];
                     acc[i] *= m[i];
                 }
             }
@@ -737,10 +739,19 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                 }
                 for (int idx2 = start; idx2 < stop; idx2++) {
                     if (idx2 == idx) continue;
-                    const double *ev = a.EV + ((size_t)idx2 * a.C + c) * a.k * n + slc;
+                    const int b2 = as_uniform(a.indices)[idx2];
+                    if (as_uniform(a.indptr)[b2] == as_uniform(a.indptr)[b2 + 1]) {
+                        double m2[K];
+                        up_stage_obs<K>(a, b2, sg, tid, xs);
+                        up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx2) * K * K, a.k, xs, tid, m2);
 #pragma unroll
-                    for (int i = 0; i < K; i++)
-                        if (i < a.k) fe[i] *= ev[(size_t)i * n];
+                        for (int i = 0; i < K; i++) fe[i] *= m2[i];
+                    } else {
+                        const double *ev = a.EV + ((size_t)idx2 * a.C + c) * a.k * n + slc;
+#pragma unroll
+                        for (int i = 0; i < K; i++)
+                            if (i < a.k) fe[i] *= ev[(size_t)i * n];
+                    }
                 }
                 const double prior = as_uniform(a.cat_prior)[c];
                 if (want_d) {
