@@ -94,8 +94,38 @@ static int query_prepare(query *q)
     if (!q->site_to_u || !q->usites || !q->w_site) return -1;
     for (long s = 0; s < S; s++) q->site_to_u[s] = -1;
     for (int i = 0; i < q->r_site.selection_len; i++) q->site_to_u[q->r_site.selection[i]] = 0;
+    /* Pattern compression: selected sites with identical observation rows share one
+     * evaluated pattern; usites[] holds one representative site per pattern, site_to_u[] maps every
+     * selected site to its pattern.  Aggregation weights are summed per pattern further down.  This is
+     * what users of the reference do by hand (the BEAST examples ship pre-compressed patterns + weights). */
     q->U = 0;
-    for (long s = 0; s < S; s++) if (q->site_to_u[s] == 0) { q->site_to_u[s] = q->U; q->usites[q->U++] = s; }
+    {
+        const size_t row_bytes = m->codes8 ? (size_t)N : (size_t)N * k * sizeof(double);
+        const unsigned char *rows = m->codes8 ? (const unsigned char *)m->codes8 : (const unsigned char *)m->prob;
+        long nsel = 0;
+        for (long s = 0; s < S; s++) if (q->site_to_u[s] == 0) nsel++;
+        size_t tsize = 16;
+        while (tsize < (size_t)nsel * 2) tsize <<= 1;
+        long *table = malloc(tsize * sizeof(long));
+        if (!table) return -1;
+        for (size_t i = 0; i < tsize; i++) table[i] = -1;
+        for (long s = 0; s < S; s++) {
+            if (q->site_to_u[s] != 0) continue;
+            const unsigned char *row = rows + (size_t)s * row_bytes;
+            unsigned long long hsh = 1469598103934665603ULL;          /* FNV-1a */
+            for (size_t b = 0; b < row_bytes; b++) { hsh ^= row[b]; hsh *= 1099511628211ULL; }
+            size_t pos = (size_t)hsh & (tsize - 1);
+            long found = -1;
+            while (table[pos] >= 0) {
+                const long p = table[pos];
+                if (!memcmp(rows + (size_t)q->usites[p] * row_bytes, row, row_bytes)) { found = p; break; }
+                pos = (pos + 1) & (tsize - 1);
+            }
+            if (found < 0) { found = q->U; table[pos] = found; q->usites[q->U++] = s; }
+            q->site_to_u[s] = found;
+        }
+        free(table);
+    }
     q->div_site = 1;
     if (q->r_site.agg_mode != AGG_NONE) host_reduction_weights(&q->r_site, q->w_site, &q->div_site);
     if (q->U == 0) return 0;
@@ -150,7 +180,11 @@ static int query_prepare(query *q)
     if (q->r_site.agg_mode != AGG_NONE) {
         double *w = malloc((size_t)U * sizeof(double));
         if (!w) return -1;
-        for (long u = 0; u < U; u++) w[u] = (double)q->w_site[q->usites[u]];
+        long double *wp = calloc((size_t)U, sizeof(long double));
+        if (!wp) { free(w); return -1; }
+        for (long s = 0; s < S; s++) if (q->site_to_u[s] >= 0) wp[q->site_to_u[s]] += q->w_site[s];
+        for (long u = 0; u < U; u++) w[u] = (double)wp[u];
+        free(wp);
         int rc = plk_set_site_weights(q->eng, w, PLK_HOST);
         free(w);
         ENG(q, rc);
