@@ -390,6 +390,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 #include "plk_fused4_asm.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
+#include "plk_updown4.h"
 
 /* ====================================================================== */
 /* K2+K3 generic: any k <= K, stack slots in HBM                           */
@@ -1293,13 +1294,18 @@ static int prepare_stream(plk_engine *h, bool fused)
                 const int nwords = ((nops + 1 + 7) / 8) * 8 + 8;
                 std::vector<unsigned> words(nwords, (unsigned)OP_END);
                 size_t oi = 0;
+                bool matvec_since_obs = false;   /* a MATVEC (full wait) ran since the last observation op */
                 for (int pc = 0; pc < nops; pc++) {
                     const int code = fops[pc].x & 0xff;
                     unsigned wv = (unsigned)code;
+                    if (code == OP_MATVEC) matvec_since_obs = true;
                     if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
                         const unsigned tn = oi + 1 < obs_t.size() ? (unsigned)obs_t[oi + 1] : 0u;
                         const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
-                        wv = (code == OP_NODE_MUL ? (unsigned)OP_TIP_MUL : (unsigned)code) | (tn << 3) | (rn << 16);
+                        /* opcode 5 in the word format = TIP_MUL that may skip its wait (plk_fused4_asm.h) */
+                        unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET : (matvec_since_obs && oi > 0 ? 5u : (unsigned)OP_TIP_MUL);
+                        wv = oc | (tn << 3) | (rn << 16);
+                        matvec_since_obs = false;
                         oi++;
                     } else if (code == OP_PUSH || code == OP_POPMUL) {
                         wv |= (unsigned)fops[pc].y << 3;
@@ -1637,6 +1643,117 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     return PLK_OK;
 }
 
+/* deriv / marginal for k = 4 with compact codes: interleaved-vector kernels (plk_updown4.h) */
+static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
+                       double *site_out, double *sums_out)
+{
+    int rc;
+    const int N = h->N, E = h->E, C = h->C;
+    const long S = h->S;
+    if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
+    const int ntips = (int)h->tip_edge.size();
+    std::vector<int> edge_tip(E, -1), edge_int(E, -1), node_int(N, -1);
+    for (int t = 0; t < ntips; t++) edge_tip[h->tip_edge[t]] = t;
+    int nie = 0, nin = 0;
+    for (int e = 0; e < E; e++) if (edge_tip[e] < 0) edge_int[e] = nie++;
+    for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a]) node_int[a] = nin++;
+    if (nin == 0) { node_int[h->preorder[0]] = nin++; }      /* a single-node tree still has a root vector */
+    std::vector<int> te = h->tip_edge;
+    te.push_back(-1);
+
+    int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
+    int *d_has = nullptr;
+    double *d_tip4 = nullptr, *d_dtip4 = nullptr;
+    auto cleanup = [&]() {
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_tip4, d_dtip4};
+        for (void *p : ps) if (p) (void)hipFree(p);
+    };
+    const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
+    if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)std::max(E, 1))) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)std::max(E, 1))) ||
+        (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
+        (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
+    if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
+    if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
+    if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
+    hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
+                       E, ntips + 1, h->nchar, d_te, h->d_Pdd, h->d_defs, d_tip4);
+    hipLaunchKernelGGL(k_build_dtip4, dim3(ntips + 1, C), dim3(64), 0, h->stream,
+                       E, ntips, h->nchar, d_te, h->d_dP, h->d_defs, d_dtip4);
+    if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
+
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
+    budget += h->work_cap * sizeof(double);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
+    if (chunk < 1) { cleanup(); h->err = "plk_deriv/plk_marginal: not enough device memory for one site"; return PLK_E_NOMEM; }
+    if (chunk < S) chunk = std::max<long>(UD4_BLOCK, chunk / UD4_BLOCK * UD4_BLOCK);
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
+
+    std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * 4 : 0, 0.0L);
+    std::vector<double> stage;
+    for (long s0 = 0; s0 < S; s0 += chunk) {
+        const long n = std::min(chunk, S - s0);
+        Up4Args a;
+        a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
+        a.N = N; a.E = E; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
+        a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
+        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni;
+        a.P = h->d_P; a.dP = h->d_dP; a.tip = d_tip4; a.dtip = d_dtip4;
+        a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
+        double *p = h->d_work;
+        a.EV = p; p += (size_t)nie * C * 4 * n;
+        a.LN = p; p += (size_t)nin * C * 4 * n;
+        a.FN = p; p += (size_t)nin * C * 4 * n;
+        a.LH = p; p += n;
+        a.DV = p; if (deriv) p += (size_t)E * n;
+        a.MV = p; if (marg) p += (size_t)N * 4 * n;
+        if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
+        const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
+        hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (deriv) hipLaunchKernelGGL((k_up4<true, false>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else hipLaunchKernelGGL((k_up4<false, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
+        if (sums_out) {
+            const double *w = h->d_w ? h->d_w + s0 : nullptr;
+            if (deriv && E > 0 && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
+            if (marg && (rc = wsum_rows(h, N * 4, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
+        }
+        if (site_out) {
+            const size_t rows = deriv ? (size_t)E : (size_t)N * 4;
+            stage.resize(rows * (size_t)n);
+            hipError_t e = hipSuccess;
+            if (rows) e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+            for (size_t r = 0; r < rows; r++)
+                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
+        }
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) { h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+    if (sums_out) {
+        const std::vector<long double> &src = deriv ? dsum : msum;
+        for (size_t r = 0; r < src.size(); r++) {
+            const double hi = (double)src[r];
+            sums_out[2 * r] = hi;
+            sums_out[2 * r + 1] = (double)(src[r] - (long double)hi);
+        }
+    }
+    return PLK_OK;
+}
+
+static bool use_updown4(const plk_engine *h)
+{
+    return !h->opt_force_generic && h->k == 4 && h->pat_mode == 1 && h->E > 0;
+}
+
 static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
                       double *site_out, double *sums_out)
 {
@@ -1645,6 +1762,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out);
+    if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out);
     const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
     const long S = h->S;
     /* padded edge-indexed streams */

@@ -145,6 +145,8 @@
         "s_and_b32 s97, s96, 7\n\t"                                                   \
         "s_cmp_eq_u32 s97, 2\n\t"                                                     \
         "s_cbranch_scc1 .Lmatvec_%=\n\t"                                              \
+        "s_cmp_eq_u32 s97, 5\n\t"                                                     \
+        "s_cbranch_scc1 .Ltipmul_nw_%=\n\t"                                           \
         "s_cmp_lt_u32 s97, 2\n\t"                                                     \
         "s_cbranch_scc1 .Ltip_%=\n\t"                                                 \
         "s_cmp_eq_u32 s97, 4\n\t"                                                     \
@@ -182,7 +184,11 @@
         ".Ltip_%=:\n\t"                                                               \
         "s_waitcnt lgkmcnt(0)\n\t"                                                    \
         "s_cmp_eq_u32 s97, 0\n\t"                                                     \
-        "s_cbranch_scc1 .Ltipset_%=\n\t"                                              \
+        "s_cbranch_scc1 .Ltipset_%=\n"                                                \
+        /* opcode 5 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which   \
+         * starts with a full wait) ran since the value was requested, so no wait is needed here \
+         * and the matrix load that MATVEC left in flight stays in flight */           \
+        ".Ltipmul_nw_%=:\n\t"                                                         \
         "v_mul_f64 v[24:25], v[24:25], v[46:47]\n\t"                                  \
         "v_mul_f64 v[26:27], v[26:27], v[48:49]\n\t"                                  \
         "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
