@@ -43,7 +43,8 @@ def _lib():
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)
-        for name in ("orc_prepare", "orc_ll", "orc_deriv", "orc_marginal", "orc_gamma_mixture"):
+        for name in ("orc_prepare", "orc_ll", "orc_deriv", "orc_marginal", "orc_gamma_mixture",
+                     "orc_frechet", "orc_edge_expect"):
             getattr(_LIB, name).restype = ctypes.c_int
     return _LIB
 
@@ -399,12 +400,18 @@ def _axis_weights(r):
 
 def _table(values, reductions, names):
     """src/ndaccum.c:198-254 (accumulate) + :382-437 (table).
-    values: ndarray over the full axes (unrequested cells may hold anything)."""
+    values: ndarray over the full axes (unrequested cells may hold anything).
+    A reduction with a `components` attribute (names, index lists) prints those
+    component indices instead of its own index (src/ndaccum.c:355-366, :401-409)."""
     arr = np.asarray(values, dtype=np.longdouble)
     keep_names = []
     for ax, (r, name) in enumerate(zip(reductions, names)):
         if r.mode == AGG_NONE:
-            keep_names.append(name)
+            comp = getattr(r, "components", None)
+            if comp is not None:
+                keep_names.extend(comp[0])
+            else:
+                keep_names.append(name)
             continue
         w, div = _axis_weights(r)
         arr = np.moveaxis(arr, ax, -1)
@@ -427,8 +434,10 @@ def _table(values, reductions, names):
         if r.mode != AGG_NONE:
             rec(ax + 1, prefix, index + [0])
         else:
+            comp = getattr(r, "components", None)
             for idx in r.selection:
-                rec(ax + 1, prefix + [idx], index + [idx])
+                label = [idx] if comp is None else [c[idx] for c in comp[1]]
+                rec(ax + 1, prefix + label, index + [idx])
 
     rec(0, [], [])
     return {"columns": keep_names + ["value"], "data": rows}
@@ -627,6 +636,204 @@ def run_marginal(root):
     return _table(vals, [r_site, r_node, r_state], ["site", "node", "state"])
 
 
+# ------------------------------------------------ dwell / trans / em-update
+def frechet(m, w, Lw, divisor=1.0, mul_by_Q=False, edge_requested=None, precise=2):
+    """Frechet matrices [C][E][k][k] (binary128 when precise == 2) for the direction
+    L = Lw / divisor (entrywise * Qn when mul_by_Q); src/util.c:501-548."""
+    lib = _lib()
+    k, E, C = m.k, m.E, w["C"]
+    Lw = np.asarray(Lw, dtype=np.longdouble).reshape(k, k)
+    hi = np.ascontiguousarray(Lw.astype(np.float64))
+    lo = np.ascontiguousarray((Lw - hi.astype(np.longdouble)).astype(np.float64))
+    Fq = np.zeros(C * max(E, 1) * k * k * 2)
+    Fd = np.zeros(C * max(E, 1) * k * k)
+    req = None
+    if edge_requested is not None:
+        edge_requested = np.ascontiguousarray(edge_requested, dtype=np.int32)
+        req = _iptr(edge_requested)
+    er = np.ascontiguousarray(m.edge_rates_csr, dtype=np.float64)
+    lib.orc_frechet(ctypes.c_int(k), ctypes.c_int(C), ctypes.c_int(E), _dptr(w["Qq"]),
+                    _dptr(w["cat_rates"]), _dptr(er), _dptr(hi), _dptr(lo),
+                    ctypes.c_double(float(divisor)), ctypes.c_int(1 if mul_by_Q else 0), req,
+                    _dptr(Fq), _dptr(Fd))
+    return Fq if precise == 2 else Fd
+
+
+def site_edge_expect(m, w, B, F, coef_mode, edge_requested=None, nthreads=0, precise=2):
+    """[S][E] (CSR edge order) conditional edge expectations for Frechet matrices F."""
+    lib = _lib()
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    S = B.shape[0]
+    out = np.zeros((S, max(m.E, 1)))
+    P = w["Pq"] if precise == 2 else np.ascontiguousarray(w["P"])
+    req = None
+    if edge_requested is not None:
+        edge_requested = np.ascontiguousarray(edge_requested, dtype=np.int32)
+        req = _iptr(edge_requested)
+    er = np.ascontiguousarray(m.edge_rates_csr, dtype=np.float64)
+    lib.orc_edge_expect(ctypes.c_int(m.N), ctypes.c_int(m.E), ctypes.c_int(m.k), ctypes.c_int(w["C"]),
+                        _iptr(m.indptr), _iptr(m.indices), _iptr(m.preorder),
+                        _dptr(P), _dptr(F), _dptr(w["cat_prior"]), _dptr(w["cat_rates"]), _dptr(er),
+                        ctypes.c_int(coef_mode),
+                        ctypes.c_int(m.root_mode), _dptr(w["root_w"]),
+                        ctypes.c_long(S), _dptr(B), None, None, req, ctypes.c_int(precise),
+                        ctypes.c_int(nthreads), _dptr(out))
+    return out[:, :m.E]
+
+
+def parse_pair_reduction(root, k, name):
+    """src/parsereduction.c:205-392 validate_column_pair_reduction"""
+    r = Reduction()
+    sel = agg = None
+    if root is not None:
+        _strict_keys(root, [], ["selection", "aggregation"], name + "_reduction")
+        sel = root.get("selection")        # an explicit null counts as absent (:13-16, :327)
+        agg = root.get("aggregation")
+    r.weights = None
+    if sel is not None:
+        if not isinstance(sel, list):
+            _fail("%s selection: should be an array" % name)
+        first, second = [], []
+        for pair in sel:
+            if not (isinstance(pair, list) and len(pair) == 2 and all(_is_int(v) for v in pair)):
+                _fail("%s selection: expected [int, int]" % name)
+            if not (0 <= pair[0] < k and 0 <= pair[1] < k):
+                _fail("%s selection: out of range" % name)
+            first.append(pair[0])
+            second.append(pair[1])
+        r.selection = list(range(len(sel)))
+        # the aggregation is validated as for a plain column reduction (:333)
+        d = {"selection": list(range(len(sel)))}
+        if "aggregation" in root:
+            d["aggregation"] = root["aggregation"]
+        tmp = parse_reduction(d, max(len(sel), 1), name)
+        r.mode, r.weights = tmp.mode, tmp.weights
+    else:
+        if agg is None:
+            r.mode = AGG_NONE
+        elif agg == "sum":
+            r.mode = AGG_SUM
+        elif agg == "avg":
+            r.mode = AGG_AVG
+        else:
+            _fail("%s reduction (no selection): only sum or avg" % name)
+        first = [a for a in range(k) for b in range(k) if a != b]
+        second = [b for a in range(k) for b in range(k) if a != b]
+        r.selection = list(range(len(first)))
+    r.n = len(r.selection)
+    r.first, r.second = first, second
+    r.components = (["first_state", "second_state"], [first, second])
+    return r
+
+
+def _edge_request(m, r_edge):
+    req = np.zeros(max(m.E, 1), dtype=np.int32)
+    for user_edge in set(r_edge.selection):
+        req[m.order[user_edge]] = 1
+    return req
+
+
+def _to_user_edges(m, d, req):
+    user = np.full((d.shape[0], m.E), np.nan)
+    for user_edge, pos in enumerate(m.order):
+        if req[pos]:
+            user[:, user_edge] = d[:, pos]
+    return user
+
+
+def run_dwell(root):
+    """src/arbplfdwell.c:303-610"""
+    _strict_keys(root, ["model_and_data"], ["site_reduction", "edge_reduction", "state_reduction"], "top level")
+    m = parse_model(root["model_and_data"])
+    r_site = _red(root, "site_reduction", m.S, "site")
+    r_edge = _red(root, "edge_reduction", m.E, "edge")
+    r_state = _red(root, "state_reduction", m.k, "state")
+    w = prepare(m)
+    sel = _selected_sites(r_site)
+    req = _edge_request(m, r_edge)
+    k = m.k
+    if r_state.mode == AGG_NONE:
+        vals = np.full((m.S, m.E, k), np.nan)
+        for state in sorted(set(r_state.selection)):
+            Lw = np.zeros((k, k))
+            Lw[state, state] = 1
+            F = frechet(m, w, Lw, 1.0, False, req)
+            if sel:
+                vals[sel, :, state] = _to_user_edges(m, site_edge_expect(m, w, m.B[sel], F, 0, req), req)
+        return _table(vals, [r_site, r_edge, r_state], ["site", "edge", "state"])
+    sw, div = _axis_weights(r_state)
+    F = frechet(m, w, np.diag(sw), div, False, req)
+    vals = np.full((m.S, m.E), np.nan)
+    if sel:
+        vals[sel] = _to_user_edges(m, site_edge_expect(m, w, m.B[sel], F, 0, req), req)
+    return _table(vals, [r_site, r_edge], ["site", "edge"])
+
+
+def run_trans(root):
+    """src/arbplftrans.c:346-660"""
+    _strict_keys(root, ["model_and_data"], ["site_reduction", "edge_reduction", "trans_reduction"], "top level")
+    m = parse_model(root["model_and_data"])
+    r_site = _red(root, "site_reduction", m.S, "site")
+    r_edge = _red(root, "edge_reduction", m.E, "edge")
+    tr = root.get("trans_reduction") if "trans_reduction" in root else None
+    if "trans_reduction" in root and tr is None:
+        _fail("trans_reduction: null")
+    r_trans = parse_pair_reduction(tr, m.k, "trans")
+    w = prepare(m)
+    sel = _selected_sites(r_site)
+    req = _edge_request(m, r_edge)
+    k = m.k
+    if r_trans.mode == AGG_NONE:
+        vals = np.full((m.S, m.E, max(r_trans.n, 1)), np.nan)
+        for t in r_trans.selection:
+            Lw = np.zeros((k, k))
+            Lw[r_trans.first[t], r_trans.second[t]] = 1
+            F = frechet(m, w, Lw, 1.0, True, req)
+            if sel:
+                vals[sel, :, t] = _to_user_edges(m, site_edge_expect(m, w, m.B[sel], F, 1, req), req)
+        return _table(vals, [r_site, r_edge, r_trans], ["site", "edge", "trans"])
+    tw, div = _axis_weights(r_trans)
+    Lw = np.zeros((k, k), dtype=np.longdouble)
+    for t in range(r_trans.n):
+        Lw[r_trans.first[t], r_trans.second[t]] += tw[t]
+    F = frechet(m, w, Lw, div, True, req)
+    vals = np.full((m.S, m.E), np.nan)
+    if sel:
+        vals[sel] = _to_user_edges(m, site_edge_expect(m, w, m.B[sel], F, 1, req), req)
+    return _table(vals, [r_site, r_edge], ["site", "edge"])
+
+
+def run_em_update(root):
+    """src/arbplfem.c:397-588: one EM update of the edge rate coefficients."""
+    _strict_keys(root, ["model_and_data"], ["site_reduction"], "top level")
+    m = parse_model(root["model_and_data"])
+    r_site = _red(root, "site_reduction", m.S, "site")
+    if r_site.mode == AGG_NONE:
+        _fail("aggregation over sites is required")
+    w = prepare(m)
+    k = m.k
+    sel = _selected_sites(r_site)
+    sw, div = _axis_weights(r_site)
+    Fd = frechet(m, w, -np.eye(k), 1.0, True)
+    Ft = frechet(m, w, 1.0 - np.eye(k), 1.0, True)
+    dwell = np.zeros(m.E, dtype=np.longdouble)
+    trans = np.zeros(m.E, dtype=np.longdouble)
+    if sel:
+        dv = site_edge_expect(m, w, m.B[sel], Fd, 2).astype(np.longdouble)
+        tv = site_edge_expect(m, w, m.B[sel], Ft, 2).astype(np.longdouble)
+        for i, site in enumerate(sel):
+            dwell += dv[i] * sw[site] / div
+            trans += tv[i] * sw[site] / div
+    rows = []
+    for user_edge, pos in enumerate(m.order):
+        if trans[pos] == 0:
+            v = 0.0
+        else:
+            v = float(trans[pos] / dwell[pos] * np.longdouble(m.edge_rates_csr[pos]))
+        rows.append([user_edge, v])
+    return {"columns": ["edge", "value"], "data": rows}
+
+
 def _string_api(fn, s):
     """src/arbplf.c:209-250: str -> str, RuntimeError on any failure."""
     try:
@@ -653,3 +860,15 @@ def arbplf_deriv(s):
 
 def arbplf_marginal(s):
     return _string_api(run_marginal, s)
+
+
+def arbplf_dwell(s):
+    return _string_api(run_dwell, s)
+
+
+def arbplf_trans(s):
+    return _string_api(run_trans, s)
+
+
+def arbplf_em_update(s):
+    return _string_api(run_em_update, s)

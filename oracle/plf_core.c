@@ -468,3 +468,94 @@ int orc_marginal(int N, int E, int k, int C,
     }
     return used;
 }
+
+/*
+ * Frechet-derivative matrices of the matrix exponential, src/util.c:501-548
+ * (_arb_mat_exp_frechet): F[c][e] = top-right k x k block of
+ * exp([[A, L], [0, A]]) with A = Qn * cat_rate_c * edge_rate_e.
+ * The direction L = (Lw_hi + Lw_lo) / divisor, multiplied entrywise by Qn when
+ * mul_by_Q is set:
+ *   dwell, one state s     Lw = e_s e_s^T                (src/arbplfdwell.c:117-157)
+ *   dwell, aggregated      Lw = diag(state weights)      (src/arbplfdwell.c:159-204)
+ *   trans, one pair (i,j)  Lw = e_i e_j^T, mul_by_Q      (src/arbplftrans.c:116-160)
+ *   trans, aggregated      Lw = summed pair weights, mul_by_Q (src/arbplftrans.c:162-224)
+ *   em-update              Lw = -I resp. 1 - I, mul_by_Q (src/arbplfem.c:100-158)
+ * Outputs: binary128 F_q_out and/or rounded F_out, [C][E][k][k]; unrequested
+ * edges are left zero.
+ */
+int orc_frechet(int k, int C, int E, const void *Qn_q, const double *cat_rates,
+                const double *edge_rates_csr, const double *Lw_hi, const double *Lw_lo,
+                double divisor, int mul_by_Q, const int *edge_requested,
+                void *F_q_out, double *F_out)
+{
+    const q128 *Q = Qn_q;
+    int n = 2 * k;
+    size_t kk = (size_t)k * k;
+    q128 *L = malloc(kk * sizeof(q128));
+    q128 *M = calloc((size_t)n * n, sizeof(q128)), *X = malloc((size_t)n * n * sizeof(q128));
+    for (size_t i = 0; i < kk; i++) {
+        L[i] = ((q128)Lw_hi[i] + (q128)(Lw_lo ? Lw_lo[i] : 0.0));
+        if (mul_by_Q) L[i] *= Q[i];
+        L[i] /= (q128)divisor;
+    }
+    for (int c = 0; c < C; c++)
+        for (int e = 0; e < E; e++) {
+            q128 *dq = F_q_out ? (q128 *)F_q_out + ((size_t)c * E + e) * kk : NULL;
+            double *dd = F_out ? F_out + ((size_t)c * E + e) * kk : NULL;
+            if (edge_requested && !edge_requested[e]) {
+                for (size_t i = 0; i < kk; i++) { if (dq) dq[i] = 0; if (dd) dd[i] = 0; }
+                continue;
+            }
+            q128 s = (q128)cat_rates[c] * (q128)edge_rates_csr[e];
+            for (int i = 0; i < k; i++)
+                for (int j = 0; j < k; j++) {
+                    M[(size_t)i * n + j] = Q[i * k + j] * s;
+                    M[(size_t)(k + i) * n + k + j] = Q[i * k + j] * s;
+                    M[(size_t)i * n + k + j] = L[i * k + j];
+                    M[(size_t)(k + i) * n + j] = 0;
+                }
+            q_expm(n, M, X);
+            for (int i = 0; i < k; i++)
+                for (int j = 0; j < k; j++) {
+                    q128 v = X[(size_t)i * n + k + j];
+                    if (dq) dq[i * k + j] = v;
+                    if (dd) dd[i * k + j] = (double)v;
+                }
+        }
+    free(L); free(M); free(X);
+    return 0;
+}
+
+/* conditional edge expectations [S][E] (CSR edge order); see site_edge_expect in plf_site.inc */
+int orc_edge_expect(int N, int E, int k, int C,
+        const int *indptr, const int *indices, const int *preorder,
+        const void *P, const void *F, const double *cat_prior, const double *cat_rates,
+        const double *edge_rates_csr, int coef_mode,
+        int root_mode, const double *root_w,
+        long S, const double *B, const uint8_t *codes, const double *defs,
+        const int *edge_requested, int precise /* 1 long double (double P, F), 2 binary128 */,
+        int nthreads, double *out /* [S][E] */)
+{
+    orc_problem pr;
+    fill_problem(&pr, N, E, k, C, indptr, indices, preorder, P, NULL, cat_prior, cat_rates,
+                 root_mode, root_w, B, codes, defs);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    int used = 1;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#endif
+        void *ws = precise == 2 ? site_ws_alloc_q(&pr) : site_ws_alloc_ld(&pr);
+#pragma omp for schedule(static)
+        for (long s = 0; s < S; s++) {
+            if (precise == 2) site_edge_expect_q(&pr, ws, s, edge_requested, F, coef_mode, edge_rates_csr, out + (size_t)s * E);
+            else site_edge_expect_ld(&pr, ws, s, edge_requested, F, coef_mode, edge_rates_csr, out + (size_t)s * E);
+        }
+        free(ws);
+    }
+    return used;
+}

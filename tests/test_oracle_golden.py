@@ -131,3 +131,48 @@ def test_path_closed_forms(oracle):
     got = {(r[1], r[2]): r[3] for r in mg}
     assert got[(1, 0)] == pytest.approx(math.exp(-u), rel=1e-15)
     assert got[(1, 1)] == pytest.approx(-math.expm1(-u), rel=1e-15)
+
+
+# ---- dwell / trans / em-update: every golden the reference holds ----
+def _pairs(kind_dirs):
+    out = []
+    for d in kind_dirs:
+        for inp in sorted(glob.glob(os.path.join(EX, d, "in*.json"))):
+            out.append((inp, os.path.join(os.path.dirname(inp), "out" + os.path.basename(inp)[2:])))
+    return out
+
+
+DWELL = _pairs(["Felsenstein.2004.fig.16.4/dwell/adenine", "Felsenstein.2004.fig.16.4/dwell/pyrimidines",
+                "BEAST.MarkovJumps/MarkovRewardsC"])
+TRANS = _pairs(["Felsenstein.2004.fig.16.4/trans/A.to.C.only", "Felsenstein.2004.fig.16.4/trans/all.types",
+                "Felsenstein.2004.fig.16.4/trans/transversions.only", "BEAST.MarkovJumps/MarkovJumpsC",
+                "BEAST.MarkovJumps/MarkovMarginalRate"])
+EM = _pairs(["Felsenstein.2004.fig.16.4/em-update/with.full.data", "Felsenstein.2004.fig.16.4/em-update/with.leaf.data",
+             "Felsenstein.2004.fig.16.4/em-update/with.no.data"])
+
+
+@pytest.mark.parametrize("inp,outp", DWELL, ids=[os.path.relpath(p[0], EX) for p in DWELL])
+def test_dwell_golden(oracle, inp, outp):
+    _compare(_run(oracle.arbplf_dwell, inp), load_json(outp), rel=2e-15)
+
+
+@pytest.mark.parametrize("inp,outp", TRANS, ids=[os.path.relpath(p[0], EX) for p in TRANS])
+def test_trans_golden(oracle, inp, outp):
+    _compare(_run(oracle.arbplf_trans, inp), load_json(outp), rel=2e-15)
+
+
+@pytest.mark.parametrize("inp,outp", EM, ids=[os.path.relpath(p[0], EX) for p in EM])
+def test_em_update_golden(oracle, inp, outp):
+    _compare(_run(oracle.arbplf_em_update, inp), load_json(outp), rel=2e-15)
+
+
+def test_markov_marginal_rate_known_answer(oracle):
+    """examples/BEAST.MarkovJumps/MarkovMarginalRate/README.md: the expectation is 12/199"""
+    got = _run(oracle.arbplf_trans, os.path.join(EX, "BEAST.MarkovJumps/MarkovMarginalRate/in.json"))
+    assert got["data"][0][-1] == pytest.approx(12 / 199, rel=1e-15)
+
+
+def test_dwell_rewards_sum_to_one(oracle):
+    """examples/BEAST.MarkovJumps/MarkovRewardsC: a reward of 1 for every state gives 1 on every branch"""
+    got = _run(oracle.arbplf_dwell, os.path.join(EX, "BEAST.MarkovJumps/MarkovRewardsC/in.json"))
+    assert all(abs(r[-1] - 1.0) <= 1e-15 for r in got["data"])
