@@ -32,10 +32,17 @@ extern "C" {
 char *arbplf_ll_string(void *userdata, const char *s_in, int *retcode);
 char *arbplf_deriv_string(void *userdata, const char *s_in, int *retcode);
 char *arbplf_marginal_string(void *userdata, const char *s_in, int *retcode);
+/* the expectation queries that reuse the same down / up passes
+ * (src/arbplfdwell.h, src/arbplftrans.h, src/arbplfem.h: arbplf_dwell_run, arbplf_trans_run,
+ * arbplf_em_update_run) */
+char *arbplf_dwell_string(void *userdata, const char *s_in, int *retcode);
+char *arbplf_trans_string(void *userdata, const char *s_in, int *retcode);
+char *arbplf_em_update_string(void *userdata, const char *s_in, int *retcode);
 
 /* Host-only validation of an input document (JSON grammar, model_and_data,
  * reductions) exactly as the corresponding query would perform it, without
- * touching the GPU.  what = "ll" | "deriv" | "marginal".  0 = accepted. */
+ * touching the GPU.  what = "ll" | "deriv" | "marginal" | "dwell" | "trans" | "em_update".
+ * 0 = accepted. */
 int arbplf_validate_string(const char *what, const char *s_in);
 
 /* stdin -> stdout filter used by the CLI mains (run_string_script,

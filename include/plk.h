@@ -132,6 +132,28 @@ int plk_deriv(plk_engine *h, const int *edge_mask,
 int plk_marginal(plk_engine *h, const int *node_mask,
                  double *site_out, double *sums_out);
 
+/*
+ * Conditional edge expectations: the shared core of arbplf-dwell, arbplf-trans
+ * and arbplf-em-update.  For a direction matrix L (k x k, given as
+ * an unevaluated sum L_hi + L_lo; L_lo may be NULL) the engine forms, per category c
+ * and edge e, the Frechet derivative of the matrix exponential
+ *     F_{c,e} = int_0^1 exp(s Qn u) L exp(s Qn (1-u)) du,   s = cat_rate_c * edge_rate_e
+ * (the top-right block of exp([[s Qn, L], [0, s Qn]]), src/util.c:501-548) and returns
+ *     x_{s,e} = sum_c prior_c * coef_{c,e} * fe_{c,e}^T F_{c,e} L_{c,b} / lhood_s
+ * (src/evaluate_site_frechet.c:5-42 and the category loops of src/arbplfdwell.c:205-300,
+ * src/arbplftrans.c:233-330, src/arbplfem.c:258-390), with coef_{c,e} =
+ *   PLK_COEF_PRIOR            1                         (dwell: L = e_s e_s^T or diag(weights))
+ *   PLK_COEF_PRIOR_RATE_EDGE  cat_rate_c * edge_rate_e  (trans: L = weights o Qn)
+ *   PLK_COEF_PRIOR_RATE       cat_rate_c                (em-update numerators / denominators)
+ * Outputs as for plk_deriv (CSR edge order, unrequested edges 0).
+ */
+enum { PLK_COEF_PRIOR = 0, PLK_COEF_PRIOR_RATE_EDGE = 1, PLK_COEF_PRIOR_RATE = 2 };
+int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
+                    const int *edge_mask, double *site_edge_out, double *edge_sums_out);
+/* the scaled Frechet matrices coef_{c,e} * F_{c,e} themselves, [C][E][k][k] host (tests) */
+int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
+                             double *F_out);
+
 /* Introspection for tests and profiling. */
 int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
 int plk_get_info(plk_engine *h, int what, long *out);

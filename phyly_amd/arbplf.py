@@ -61,6 +61,21 @@ def arbplf_marginal(s):
     return _call("arbplf_marginal", s)
 
 
+def arbplf_dwell(s):
+    """conditional expected dwell proportions per edge and state (src/arbplfdwell.c:569-610)"""
+    return _call("arbplf_dwell", s)
+
+
+def arbplf_trans(s):
+    """conditional expected labelled transition counts per edge (src/arbplftrans.c:617-660)"""
+    return _call("arbplf_trans", s)
+
+
+def arbplf_em_update(s):
+    """one EM update of the edge rate coefficients (src/arbplfem.c:548-588)"""
+    return _call("arbplf_em_update", s)
+
+
 def _out_of_scope(name):
     def f(s):
         raise RuntimeError("arbplf likelihood error: %s is outside the MI355X hot path of this build" % name)
@@ -69,6 +84,6 @@ def _out_of_scope(name):
 
 
 # the reference module's other entry points (src/arbplf.c:521-534) are out of scope
-for _name in ("arbplf_hess", "arbplf_inv_hess", "arbplf_dwell", "arbplf_trans", "arbplf_em_update",
+for _name in ("arbplf_hess", "arbplf_inv_hess",
               "arbplf_newton_delta", "arbplf_newton_update", "arbplf_newton_refine"):
     globals()[_name] = _out_of_scope(_name)

@@ -49,6 +49,7 @@ void arbplf_shutdown(void)
 typedef struct {
     host_model m;
     host_reduction r_site, r_a, r_b;   /* site + up to two further axes */
+    int *pair_first, *pair_second;     /* trans_reduction: state pairs parallel to r_b.selection */
     /* prepared model */
     int C;
     double *cat_rates, *cat_prior, *pi, *Qn, *Qn_lo;
@@ -77,6 +78,7 @@ static void query_clear(query *q)
     host_reduction_clear(&q->r_b);
     free(q->cat_rates); free(q->cat_prior); free(q->pi); free(q->Qn); free(q->Qn_lo);
     free(q->usites); free(q->site_to_u); free(q->w_site);
+    free(q->pair_first); free(q->pair_second);
 }
 
 #define ENG(q, call) do { if (call) { fprintf(stderr, "error: %s\n", plk_last_error((q)->eng)); return -1; } } while (0)
@@ -215,20 +217,30 @@ static int check_finite(double v, const char *what)
     return -1;
 }
 
-/* _parse of the three drivers: kind 0 ll, 1 deriv, 2 marginal
- * (src/arbplfll.c:250-288, src/arbplfderiv.c:445-493, src/arbplfmarginal.c:348-405) */
+/* _parse of the drivers: kind 0 ll, 1 deriv, 2 marginal, 3 dwell, 4 trans, 5 em-update
+ * (src/arbplfll.c:250-288, src/arbplfderiv.c:445-493, src/arbplfmarginal.c:348-405,
+ *  src/arbplfdwell.c:507-566, src/arbplftrans.c:553-614, src/arbplfem.c:505-545) */
 static int query_parse(query *q, int kind, const jval *root)
 {
     static const char *const req[] = {"model_and_data", NULL};
     static const char *const all_ll[] = {"model_and_data", "site_reduction", NULL};
     static const char *const all_deriv[] = {"model_and_data", "site_reduction", "edge_reduction", NULL};
     static const char *const all_marg[] = {"model_and_data", "site_reduction", "node_reduction", "state_reduction", NULL};
-    if (host_check_keys(root, req, kind == 0 ? all_ll : kind == 1 ? all_deriv : all_marg, "input")) return -1;
+    static const char *const all_dwell[] = {"model_and_data", "site_reduction", "edge_reduction", "state_reduction", NULL};
+    static const char *const all_trans[] = {"model_and_data", "site_reduction", "edge_reduction", "trans_reduction", NULL};
+    const char *const *allowed = kind == 0 ? all_ll : kind == 1 ? all_deriv : kind == 2 ? all_marg :
+                                 kind == 3 ? all_dwell : kind == 4 ? all_trans : all_ll;
+    if (host_check_keys(root, req, allowed, "input")) return -1;
     if (host_model_parse(&q->m, j_get(root, "model_and_data"))) return -1;
     if (host_reduction_parse(&q->r_site, (int)q->m.S, "site", j_get(root, "site_reduction"))) return -1;
     if (kind == 1 && host_reduction_parse(&q->r_a, q->m.E, "edge", j_get(root, "edge_reduction"))) return -1;
     if (kind == 2 && host_reduction_parse(&q->r_a, q->m.N, "node", j_get(root, "node_reduction"))) return -1;
     if (kind == 2 && host_reduction_parse(&q->r_b, q->m.k, "state", j_get(root, "state_reduction"))) return -1;
+    if ((kind == 3 || kind == 4) && host_reduction_parse(&q->r_a, q->m.E, "edge", j_get(root, "edge_reduction"))) return -1;
+    if (kind == 3 && host_reduction_parse(&q->r_b, q->m.k, "state", j_get(root, "state_reduction"))) return -1;
+    if (kind == 4 && host_pair_reduction_parse(&q->r_b, &q->pair_first, &q->pair_second, q->m.k, "trans",
+                                               j_get(root, "trans_reduction"))) return -1;
+    if (kind == 5 && q->r_site.agg_mode == AGG_NONE) { fprintf(stderr, "error: aggregation over sites is required\n"); return -1; }
     return 0;
 }
 
@@ -423,6 +435,195 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------ dwell / trans */
+/* split a long double into an unevaluated (hi, lo) pair of doubles */
+static void split_ld(long double v, double *hi, double *lo)
+{
+    *hi = (double)v;
+    *lo = isfinite(*hi) ? (double)(v - (long double)*hi) : 0.0;
+}
+
+/*
+ * arbplf-dwell (kind 3, src/arbplfdwell.c:303-505) and arbplf-trans (kind 4, src/arbplftrans.c:346-551).
+ * The third axis (states / state pairs) is either aggregated -- then its weights go into the one
+ * direction matrix L ("linear algebra trick", src/arbplfdwell.c:159-204, src/arbplftrans.c:162-224) --
+ * or listed, one engine pass per selected state / pair (src/arbplfdwell.c:117-157, src/arbplftrans.c:116-160).
+ */
+static int run_edge_expect(const jval *root, jbuf *out, int kind)
+{
+    query q;
+    int rc = -1;
+    int *mask = NULL;
+    double **vals = NULL, **sums = NULL, *Lhi = NULL, *Llo = NULL;
+    long double *w_edge = NULL, *w_third = NULL, *Lacc = NULL;
+    int npass = 0;
+    query_init(&q);
+    if (query_parse(&q, kind, root)) goto done;
+    if (query_prepare(&q)) goto done;
+    const int E = q.m.E, k = q.m.k;
+    const host_reduction *re = &q.r_a, *rt = &q.r_b;
+    const int site_agg = q.r_site.agg_mode != AGG_NONE, edge_agg = re->agg_mode != AGG_NONE, third_agg = rt->agg_mode != AGG_NONE;
+    const int coef = kind == 3 ? PLK_COEF_PRIOR : PLK_COEF_PRIOR_RATE_EDGE;
+    mask = calloc(E + 1, sizeof(int));
+    w_edge = malloc((size_t)(E + 1) * sizeof(long double));
+    w_third = malloc((size_t)(rt->n + 1) * sizeof(long double));
+    Lhi = calloc((size_t)k * k + 1, sizeof(double));
+    Llo = calloc((size_t)k * k + 1, sizeof(double));
+    Lacc = calloc((size_t)k * k + 1, sizeof(long double));
+    if (!mask || !w_edge || !w_third || !Lhi || !Llo || !Lacc) goto done;
+    for (int i = 0; i < re->selection_len; i++) mask[q.m.edge_order[re->selection[i]]] = 1;
+    long double div_edge = 1, div_third = 1;
+    if (edge_agg) host_reduction_weights(re, w_edge, &div_edge);
+    if (third_agg) host_reduction_weights(rt, w_third, &div_third);
+    npass = third_agg ? 1 : rt->selection_len;
+    vals = calloc((size_t)npass + 1, sizeof(double *));
+    sums = calloc((size_t)npass + 1, sizeof(double *));
+    if (!vals || !sums) goto done;
+    for (int t = 0; t < npass; t++) {
+        /* direction matrix; for trans its entries are multiplied by the normalised rates
+         * (src/arbplftrans.c:137-138, :196), hi/lo parts of Qn included */
+        for (int i = 0; i < k * k; i++) Lacc[i] = 0;
+        if (third_agg) {
+            for (int x = 0; x < rt->n; x++) {
+                if (w_third[x] == 0) continue;
+                const int a = kind == 3 ? x : q.pair_first[x], b = kind == 3 ? x : q.pair_second[x];
+                Lacc[a * k + b] += w_third[x];
+            }
+        } else {
+            const int x = rt->selection[t];
+            const int a = kind == 3 ? x : q.pair_first[x], b = kind == 3 ? x : q.pair_second[x];
+            Lacc[a * k + b] = 1;
+        }
+        if (q.U > 0)
+            for (int i = 0; i < k * k; i++) {
+                long double v = Lacc[i];
+                if (kind == 4) v *= (long double)q.Qn[i] + (long double)q.Qn_lo[i];
+                v /= div_third;
+                split_ld(v, &Lhi[i], &Llo[i]);
+            }
+        if (site_agg) {
+            sums[t] = calloc((size_t)E * 2 + 2, sizeof(double));
+            if (!sums[t]) goto done;
+            if (q.U > 0 && re->selection_len > 0 && plk_edge_expect(q.eng, Lhi, Llo, coef, mask, NULL, sums[t])) {
+                fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
+            }
+        } else {
+            vals[t] = calloc((size_t)q.U * E + 1, sizeof(double));
+            if (!vals[t]) goto done;
+            if (q.U > 0 && re->selection_len > 0 && plk_edge_expect(q.eng, Lhi, Llo, coef, mask, vals[t], NULL)) {
+                fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
+            }
+        }
+    }
+    /* table header; the trans axis prints its two component indices (src/ndaccum.c:355-366, :401-409) */
+    jbuf_puts(out, "{\"columns\": [");
+    if (!site_agg) jbuf_puts(out, "\"site\", ");
+    if (!edge_agg) jbuf_puts(out, "\"edge\", ");
+    if (!third_agg) jbuf_puts(out, kind == 3 ? "\"state\", " : "\"first_state\", \"second_state\", ");
+    jbuf_puts(out, "\"value\"], \"data\": [");
+    int first = 1;
+    const int nsite_rows = site_agg ? 1 : q.r_site.selection_len;
+    const int nedge_rows = edge_agg ? 1 : re->selection_len;
+    for (int si = 0; si < nsite_rows; si++) {
+        const int s = site_agg ? -1 : q.r_site.selection[si];
+        const long u = site_agg ? -1 : q.site_to_u[s];
+        for (int ei = 0; ei < nedge_rows; ei++) {
+            for (int t = 0; t < npass; t++) {
+                long double v = 0;
+                if (edge_agg) {
+                    for (int ue = 0; ue < E; ue++) {
+                        if (w_edge[ue] == 0) continue;
+                        const int ce = q.m.edge_order[ue];
+                        long double x = site_agg ? ((long double)sums[t][2 * ce] + (long double)sums[t][2 * ce + 1]) / q.div_site
+                                                 : (long double)vals[t][(size_t)u * E + ce];
+                        v += x * w_edge[ue] / div_edge;
+                    }
+                } else {
+                    const int ce = q.m.edge_order[re->selection[ei]];
+                    v = site_agg ? ((long double)sums[t][2 * ce] + (long double)sums[t][2 * ce + 1]) / q.div_site
+                                 : (long double)vals[t][(size_t)u * E + ce];
+                }
+                double d = clean(v);
+                if (check_finite(d, kind == 3 ? "a dwell expectation" : "a transition count expectation")) goto done;
+                if (!first) jbuf_puts(out, ", ");
+                first = 0;
+                jbuf_puts(out, "[");
+                if (!site_agg) { jbuf_int(out, s); jbuf_puts(out, ", "); }
+                if (!edge_agg) { jbuf_int(out, re->selection[ei]); jbuf_puts(out, ", "); }
+                if (!third_agg) {
+                    const int x = rt->selection[t];
+                    if (kind == 3) { jbuf_int(out, x); jbuf_puts(out, ", "); }
+                    else { jbuf_int(out, q.pair_first[x]); jbuf_puts(out, ", "); jbuf_int(out, q.pair_second[x]); jbuf_puts(out, ", "); }
+                }
+                jbuf_real(out, d);
+                jbuf_puts(out, "]");
+            }
+        }
+    }
+    jbuf_puts(out, "]}");
+    rc = 0;
+done:
+    if (vals) for (int t = 0; t < npass; t++) free(vals[t]);
+    if (sums) for (int t = 0; t < npass; t++) free(sums[t]);
+    free(vals); free(sums); free(mask); free(w_edge); free(w_third); free(Lhi); free(Llo); free(Lacc);
+    query_clear(&q);
+    return rc;
+}
+
+static int run_dwell(const jval *root, jbuf *out) { return run_edge_expect(root, out, 3); }
+static int run_trans(const jval *root, jbuf *out) { return run_edge_expect(root, out, 4); }
+
+/* ------------------------------------------------------------------ em-update */
+/* arbplf-em-update (src/arbplfem.c:397-503): edge_rate_e * E[transitions on e] / E[rate-weighted dwell on e],
+ * both accumulated over the weighted sites; exactly 0 where the expected transition count is 0. */
+static int run_em_update(const jval *root, jbuf *out)
+{
+    query q;
+    int rc = -1;
+    double *Lhi = NULL, *Llo = NULL, *dw = NULL, *tr = NULL;
+    query_init(&q);
+    if (query_parse(&q, 5, root)) goto done;
+    if (query_prepare(&q)) goto done;
+    const int E = q.m.E, k = q.m.k;
+    Lhi = calloc((size_t)k * k + 1, sizeof(double));
+    Llo = calloc((size_t)k * k + 1, sizeof(double));
+    dw = calloc((size_t)E * 2 + 2, sizeof(double));
+    tr = calloc((size_t)E * 2 + 2, sizeof(double));
+    if (!Lhi || !Llo || !dw || !tr) goto done;
+    if (q.U > 0 && E > 0) {
+        /* L_dwell: exit rates on the diagonal; L_trans: rates off the diagonal (src/arbplfem.c:118-129) */
+        for (int i = 0; i < k; i++)
+            for (int j = 0; j < k; j++) {
+                Lhi[i * k + j] = i == j ? -q.Qn[i * k + j] : 0.0;
+                Llo[i * k + j] = i == j ? -q.Qn_lo[i * k + j] : 0.0;
+            }
+        if (plk_edge_expect(q.eng, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, dw)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        for (int i = 0; i < k; i++)
+            for (int j = 0; j < k; j++) {
+                Lhi[i * k + j] = i != j ? q.Qn[i * k + j] : 0.0;
+                Llo[i * k + j] = i != j ? q.Qn_lo[i * k + j] : 0.0;
+            }
+        if (plk_edge_expect(q.eng, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, tr)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+    }
+    jbuf_puts(out, "{\"columns\": [\"edge\", \"value\"], \"data\": [");
+    for (int ue = 0; ue < E; ue++) {
+        const int ce = q.m.edge_order[ue];
+        const long double t = (long double)tr[2 * ce] + (long double)tr[2 * ce + 1];
+        const long double d = (long double)dw[2 * ce] + (long double)dw[2 * ce + 1];
+        double v = 0.0;
+        if (t != 0) v = clean(t / d * (long double)q.m.edge_rates_csr[ce]);
+        if (check_finite(v, "an updated edge rate coefficient")) goto done;
+        if (ue) jbuf_puts(out, ", ");
+        jbuf_puts(out, "["); jbuf_int(out, ue); jbuf_puts(out, ", "); jbuf_real(out, v); jbuf_puts(out, "]");
+    }
+    jbuf_puts(out, "]}");
+    rc = 0;
+done:
+    free(Lhi); free(Llo); free(dw); free(tr);
+    query_clear(&q);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ string API */
 static char *string_hom(int (*run)(const jval *, jbuf *), void *userdata, const char *s_in, int *retcode)
 {
@@ -453,13 +654,17 @@ static char *string_hom(int (*run)(const jval *, jbuf *), void *userdata, const 
 char *arbplf_ll_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_ll, userdata, s_in, retcode); }
 char *arbplf_deriv_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_deriv, userdata, s_in, retcode); }
 char *arbplf_marginal_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_marginal, userdata, s_in, retcode); }
+char *arbplf_dwell_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_dwell, userdata, s_in, retcode); }
+char *arbplf_trans_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_trans, userdata, s_in, retcode); }
+char *arbplf_em_update_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_em_update, userdata, s_in, retcode); }
 
 /* Host-only validation (JSON grammar, model, reductions); no GPU is touched.
- * what: "ll", "deriv" or "marginal".  Returns 0 when the input would be accepted. */
+ * what: "ll", "deriv", "marginal", "dwell", "trans" or "em_update".  Returns 0 when the input would be accepted. */
 int arbplf_validate_string(const char *what, const char *s_in)
 {
     char err[256];
-    int kind = !strcmp(what, "ll") ? 0 : !strcmp(what, "deriv") ? 1 : !strcmp(what, "marginal") ? 2 : -1;
+    int kind = !strcmp(what, "ll") ? 0 : !strcmp(what, "deriv") ? 1 : !strcmp(what, "marginal") ? 2 :
+               !strcmp(what, "dwell") ? 3 : !strcmp(what, "trans") ? 4 : !strcmp(what, "em_update") ? 5 : -1;
     if (kind < 0 || !s_in) return -1;
     json_doc *doc = json_doc_parse(s_in, err, sizeof err);
     if (!doc) { fprintf(stderr, "%s\n", err); return -1; }

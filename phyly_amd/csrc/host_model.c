@@ -320,6 +320,32 @@ void host_reduction_init(host_reduction *r) { memset(r, 0, sizeof(*r)); }
 void host_reduction_clear(host_reduction *r) { free(r->selection); free(r->weights); memset(r, 0, sizeof(*r)); }
 
 /* src/parsereduction.c:20-195 */
+/* src/parsereduction.c:84-159 _validate_column_aggregation */
+static int reduction_parse_aggregation(host_reduction *r, const char *name, const jval *agg)
+{
+    if (!agg) r->agg_mode = AGG_NONE;
+    else if (j_is_string(agg)) {
+        if (!strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
+        else if (!strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
+        else if (!strcmp(agg->u.s, "only")) {
+            if (r->selection_len != 1) FAILF("error: %s aggregation (\"only\"): the selection length must be exactly 1 (selection_len = %d)\n", name, r->selection_len);
+            r->agg_mode = AGG_ONLY;
+        } else FAILF("error: %s aggregation (string): the only valid aggregation strings are {\"sum\", \"avg\", \"only\"}\n", name);
+    } else if (j_is_array(agg)) {
+        r->agg_mode = AGG_WEIGHTED_SUM;
+        if ((int)j_len(agg) != r->selection_len) FAILF("error: %s aggregation (weighted sum): the number of weights must be equal to the number of selected %s indices\n", name, name);
+        r->weights = malloc((size_t)(r->selection_len + 1) * sizeof(double));
+        if (!r->weights) return -1;
+        for (int i = 0; i < r->selection_len; i++) {
+            const jval *x = j_at(agg, i);
+            if (!j_is_number(x)) FAILF("error: %s aggregation (weighted sum): weights should be numeric\n", name);
+            r->weights[i] = j_number(x);
+        }
+    } else FAILF("error: %s aggregation: if provided, the aggregation should be a string or an array of numeric weights\n", name);
+    if (r->agg_mode == AGG_AVG && r->selection_len == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
+    return 0;
+}
+
 int host_reduction_parse(host_reduction *r, int n, const char *name, const jval *root)
 {
     static const char *const none[] = {NULL};
@@ -349,26 +375,62 @@ int host_reduction_parse(host_reduction *r, int n, const char *name, const jval 
             r->selection[i] = (int)x->u.i;
         }
     }
-    if (!agg) r->agg_mode = AGG_NONE;
-    else if (j_is_string(agg)) {
-        if (!strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
-        else if (!strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
-        else if (!strcmp(agg->u.s, "only")) {
-            if (r->selection_len != 1) FAILF("error: %s aggregation (\"only\"): the selection length must be exactly 1 (selection_len = %d)\n", name, r->selection_len);
-            r->agg_mode = AGG_ONLY;
-        } else FAILF("error: %s aggregation (string): the only valid aggregation strings are {\"sum\", \"avg\", \"only\"}\n", name);
-    } else if (j_is_array(agg)) {
-        r->agg_mode = AGG_WEIGHTED_SUM;
-        if ((int)j_len(agg) != r->selection_len) FAILF("error: %s aggregation (weighted sum): the number of weights must be equal to the number of selected %s indices\n", name, name);
-        r->weights = malloc((size_t)(r->selection_len + 1) * sizeof(double));
-        if (!r->weights) return -1;
-        for (int i = 0; i < r->selection_len; i++) {
-            const jval *x = j_at(agg, i);
-            if (!j_is_number(x)) FAILF("error: %s aggregation (weighted sum): weights should be numeric\n", name);
-            r->weights[i] = j_number(x);
+    return reduction_parse_aggregation(r, name, agg);
+}
+
+/* src/parsereduction.c:205-392 validate_column_pair_reduction: a selection of [first, second] state
+ * pairs; without a selection every ordered pair of distinct states is selected and only
+ * "sum" / "avg" (or no aggregation) are allowed.  r->selection[i] = i; *first / *second are
+ * malloc'd arrays of r->selection_len entries. */
+int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int k, const char *name, const jval *root)
+{
+    static const char *const none[] = {NULL};
+    static const char *const all[] = {"selection", "aggregation", NULL};
+    const jval *sel = NULL, *agg = NULL;
+    *first = *second = NULL;
+    if (root) {
+        if (host_check_keys(root, none, all, "reduction")) return -1;
+        sel = j_get(root, "selection");
+        agg = j_get(root, "aggregation");
+        if (j_is_null(sel)) sel = NULL;      /* _exists(): an explicit null counts as absent (:13-16) */
+    }
+    if (sel) {
+        if (!j_is_array(sel)) FAILF("error: %s selection: the selection should be an array\n", name);
+        const int n = (int)j_len(sel);
+        r->n = n;
+        r->selection_len = n;
+        r->selection = malloc((size_t)(n + 1) * sizeof(int));
+        *first = malloc((size_t)(n + 1) * sizeof(int));
+        *second = malloc((size_t)(n + 1) * sizeof(int));
+        if (!r->selection || !*first || !*second) return -1;
+        for (int i = 0; i < n; i++) {
+            const jval *p = j_at(sel, i);
+            if (!j_is_array(p) || j_len(p) != 2 || !j_is_int(j_at(p, 0)) || !j_is_int(j_at(p, 1)))
+                FAILF("error: %s selection: each entry must be a pair of integers\n", name);
+            const long a = j_at(p, 0)->u.i, b = j_at(p, 1)->u.i;
+            if (a < 0 || a >= k || b < 0 || b >= k)
+                FAILF("error: %s selection: indices should be nonnegative integers less than the number of column elements\n", name);
+            (*first)[i] = (int)a; (*second)[i] = (int)b;
+            r->selection[i] = i;
         }
-    } else FAILF("error: %s aggregation: if provided, the aggregation should be a string or an array of numeric weights\n", name);
-    if (r->agg_mode == AGG_AVG && r->selection_len == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
+        return reduction_parse_aggregation(r, name, agg);
+    }
+    if (!agg || j_is_null(agg)) r->agg_mode = AGG_NONE;
+    else if (j_is_string(agg) && !strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
+    else if (j_is_string(agg) && !strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
+    else FAILF("error: %s reduction (no selection): if no selection is specified, the only allowed aggregations are \"sum\" or \"avg\"\n", name);
+    const int n = k * (k - 1);
+    r->n = n;
+    r->selection_len = n;
+    r->selection = malloc((size_t)(n + 1) * sizeof(int));
+    *first = malloc((size_t)(n + 1) * sizeof(int));
+    *second = malloc((size_t)(n + 1) * sizeof(int));
+    if (!r->selection || !*first || !*second) return -1;
+    int i = 0;
+    for (int a = 0; a < k; a++)
+        for (int b = 0; b < k; b++)
+            if (a != b) { r->selection[i] = i; (*first)[i] = a; (*second)[i] = b; i++; }
+    if (r->agg_mode == AGG_AVG && n == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
     return 0;
 }
 

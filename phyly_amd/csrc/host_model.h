@@ -64,6 +64,8 @@ void host_reduction_init(host_reduction *r);
 void host_reduction_clear(host_reduction *r);
 /* root may be NULL (key absent) */
 int host_reduction_parse(host_reduction *r, int n, const char *name, const jval *root);
+/* selection of [first, second] state pairs (trans_reduction); caller frees *first / *second */
+int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int k, const char *name, const jval *root);
 /* per-index aggregation weight (long double) and divisor; weights must hold n entries */
 void host_reduction_weights(const host_reduction *r, long double *weights, long double *divisor);
 

@@ -188,23 +188,50 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 
 #define EXPM_TERMS 28
 
-__global__ __launch_bounds__(1024) void k_expm_dd(int k, int E, const double *__restrict__ Qn /* [2][k*k]: hi then lo */,
+/*
+ * FRECHET = false: P = exp(s Qn), s = r_c t_e; outputs unrounded / rounded P and dP = r_c Qn P.
+ * FRECHET = true: the 2k x 2k block matrix [[s Qn, L], [0, s Qn]] is exponentiated instead and the
+ * top-right block -- the Frechet derivative of exp at s Qn in direction L, i.e.
+ * int_0^1 exp(s Qn u) L exp(s Qn (1-u)) du (src/util.c:501-548) -- is written to Fout, scaled by
+ * coef = 1 (PLK_COEF_PRIOR), s (PLK_COEF_PRIOR_RATE_EDGE) or r_c (PLK_COEF_PRIOR_RATE).
+ */
+template <bool FRECHET>
+__global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *__restrict__ Qn /* [2][ks*ks]: hi then lo */,
                           const double *__restrict__ edge_rates,
                           const double *__restrict__ cat_rates,
                           dd *__restrict__ Pdd, double *__restrict__ P, double *__restrict__ dP,
-                          dd *gscratch, int use_lds)
+                          dd *gscratch, int use_lds,
+                          const double *__restrict__ Lm /* [2][ks*ks] */, int coef_mode,
+                          const int *__restrict__ edge_mask, double *__restrict__ Fout)
 {
     extern __shared__ double smem_raw[];
-    __shared__ double s_row[PLK_MAX_K];
+    __shared__ double s_row[2 * PLK_MAX_K];
     __shared__ int s_sq;
     const int ce = blockIdx.x;
     const int c = ce / E, e = ce - c * E;
-    const int kk = k * k;
+    const int k = FRECHET ? 2 * ks : ks;
+    const int kk = k * k, kks = ks * ks;
+    if (FRECHET && edge_mask && !edge_mask[e]) {
+        for (int idx = threadIdx.x; idx < kks; idx += blockDim.x) Fout[(size_t)ce * kks + idx] = 0.0;
+        return;
+    }
     dd *base = use_lds ? reinterpret_cast<dd *>(smem_raw) : gscratch + (size_t)ce * 4 * kk;
     dd *X = base, *T = base + kk, *O = base + 2 * kk, *W = base + 3 * kk;
 
     const dd s = dd_two_prod(cat_rates[c], edge_rates[e]);
-    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_mul(s, dd_make(Qn[idx], Qn[kk + idx]));
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+        if (!FRECHET) {
+            X[idx] = dd_mul(s, dd_make(Qn[idx], Qn[kk + idx]));
+        } else {
+            const int i = idx / k, j = idx - i * k;
+            const int bi = i >= ks, bj = j >= ks;
+            const int q = (i - bi * ks) * ks + (j - bj * ks);
+            dd v = dd_make(0.0, 0.0);
+            if (bi == bj) v = dd_mul(s, dd_make(Qn[q], Qn[kks + q]));
+            else if (!bi) v = dd_make(Lm[q], Lm[kks + q]);
+            X[idx] = v;
+        }
+    }
     __syncthreads();
     if ((int)threadIdx.x < k) {
         double r = 0;
@@ -245,8 +272,18 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int k, int E, const double *__
         for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = W[idx];
         __syncthreads();
     }
-    /* outputs: unrounded P, rounded P, rounded dP = r_c * Qn * P */
     const double rc = cat_rates[c];
+    if (FRECHET) {
+        for (int idx = threadIdx.x; idx < kks; idx += blockDim.x) {
+            const int i = idx / ks, j = idx - i * ks;
+            dd v = O[i * k + ks + j];
+            if (coef_mode == PLK_COEF_PRIOR_RATE_EDGE) v = dd_mul(v, s);
+            else if (coef_mode == PLK_COEF_PRIOR_RATE) v = dd_mul_d(v, rc);
+            Fout[(size_t)ce * kks + idx] = v.hi;
+        }
+        return;
+    }
+    /* outputs: unrounded P, rounded P, rounded dP = r_c * Qn * P */
     for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
         dd v = O[idx];
         if (v.hi < 0) v = dd_make(0.0, 0.0);
@@ -533,6 +570,7 @@ struct UpArgs {
     long S, Spad;        /* full pattern extent (row pitch of codes / B) */
     long s0, n;          /* chunk [s0, s0+n) */
     int N, E, k, C, nchar, pat_mode, root_mode;
+    int dzero;           /* 1: the edge-form matrices have zero row sums (dP): exact zero for constant inputs */
     const int *indptr, *indices, *preorder;
     const int *node_has_data;  /* N */
     const double *PT;    /* [C][E][K*K] transposed P:  PT[j*K+i] = P[i][j]  */
@@ -763,7 +801,8 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                         for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
                     }
                     double y[K];
-                    up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
+                    if (a.dzero) up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
+                    else up_matvec<K, 0>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
                     double d = 0.0;
 #pragma unroll
                     for (int i = 0; i < K; i++) d = fma(fe[i], y[i], d);
@@ -970,9 +1009,9 @@ static int run_expm(plk_engine *h)
     if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * 4 * kk))) return rc; }
     /* one thread per few matrix entries: the dd matrix products are the whole cost for k = 61 */
     const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
-    hipLaunchKernelGGL(k_expm_dd, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+    hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
-                       h->d_scratch, use_lds);
+                       h->d_scratch, use_lds, (const double *)nullptr, 0, (const int *)nullptr, (double *)nullptr);
     HIPCHK(h, hipGetLastError());
     h->model_dirty = false;
     h->stream_dirty = true;
@@ -1531,7 +1570,7 @@ static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, unsigned grid, s
 
 /* deriv / marginal for 9 <= k <= 64 with compact codes: matrix-core kernels (plk_mfma_updown.h) */
 static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
-                           double *site_out, double *sums_out)
+                           double *site_out, double *sums_out, const double *d_M, int dzero)
 {
     int rc;
     const int N = h->N, E = h->E, k = h->k, C = h->C;
@@ -1568,11 +1607,11 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_P, d_fP);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 1, h->d_P, d_fPT);
-    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_dP, d_fD);
+    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, d_M, d_fD);
     hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
                        k, R, E, ntips, h->nchar, d_te, h->d_Pdd, h->d_defs, h->K, d_tipd);
     hipLaunchKernelGGL(k_build_dtip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
-                       k, R, E, ntips, h->nchar, d_te, h->d_dP, h->d_defs, h->K, d_dtip);
+                       k, R, E, ntips, h->nchar, d_te, d_M, h->d_defs, h->K, d_dtip, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
     const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
@@ -1594,6 +1633,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         MUpArgs a;
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.k = k; a.kk4 = kk4; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
+        a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni;
         a.fragP = d_fP; a.fragPT = d_fPT; a.fragD = d_fD; a.tip = d_tipd; a.dtip = d_dtip;
@@ -1645,7 +1685,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
 
 /* deriv / marginal for k = 4 with compact codes: interleaved-vector kernels (plk_updown4.h) */
 static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
-                       double *site_out, double *sums_out)
+                       double *site_out, double *sums_out, const double *d_M, int dzero)
 {
     int rc;
     const int N = h->N, E = h->E, C = h->C;
@@ -1679,7 +1719,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
                        E, ntips + 1, h->nchar, d_te, h->d_Pdd, h->d_defs, d_tip4);
     hipLaunchKernelGGL(k_build_dtip4, dim3(ntips + 1, C), dim3(64), 0, h->stream,
-                       E, ntips, h->nchar, d_te, h->d_dP, h->d_defs, d_dtip4);
+                       E, ntips, h->nchar, d_te, d_M, h->d_defs, d_dtip4, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
     const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
@@ -1700,9 +1740,10 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         Up4Args a;
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
+        a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni;
-        a.P = h->d_P; a.dP = h->d_dP; a.tip = d_tip4; a.dtip = d_dtip4;
+        a.P = h->d_P; a.dP = d_M; a.tip = d_tip4; a.dtip = d_dtip4;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
         double *p = h->d_work;
         a.EV = p; p += (size_t)nie * C * 4 * n;
@@ -1754,15 +1795,18 @@ static bool use_updown4(const plk_engine *h)
     return !h->opt_force_generic && h->k == 4 && h->pat_mode == 1 && h->E > 0;
 }
 
+/* d_M: the per-(category, edge) matrices of the edge bilinear form fe^T M L_b: dP for the derivative
+ * (dzero = 1: rows sum to zero), scaled Frechet matrices for dwell / trans / em-update (dzero = 0) */
 static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
-                      double *site_out, double *sums_out)
+                      double *site_out, double *sums_out, const double *d_M_in = nullptr, int dzero = 1)
 {
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_deriv/plk_marginal: tree, model and patterns must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
-    if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out);
-    if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out);
+    const double *d_M = d_M_in ? d_M_in : h->d_dP;
+    if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
+    if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
     const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
     const long S = h->S;
     /* padded edge-indexed streams */
@@ -1782,7 +1826,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     const int bt = K * K >= 256 ? 256 : 64;
     hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_P, d_PT);
     hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 1, h->d_P, d_PN);
-    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_dP, d_DT);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, d_M, d_DT);
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
@@ -1807,6 +1851,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         UpArgs a;
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
+        a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
@@ -1864,6 +1909,83 @@ extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_
 {
     if (!h) return PLK_E_ARG;
     return run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out);
+}
+
+/* Conditional edge expectations (dwell / trans / em-update numerators): replaces
+ * src/evaluate_site_frechet.c:5-42 + the Frechet matrix set-up of src/arbplfdwell.c:117-204,
+ * src/arbplftrans.c:116-224, src/arbplfem.c:100-158. */
+extern "C" int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
+                               const int *edge_mask, double *site_edge_out, double *edge_sums_out)
+{
+    if (!h) return PLK_E_ARG;
+    if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_edge_expect: tree, model and patterns must be set"; return PLK_E_ARG; }
+    if (!L_hi || coef_mode < PLK_COEF_PRIOR || coef_mode > PLK_COEF_PRIOR_RATE) { h->err = "plk_edge_expect: bad direction matrix or coefficient mode"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    const int k = h->k, C = h->C, E = h->E;
+    if (E == 0) return PLK_OK;
+    const size_t kk = (size_t)k * k, n2 = 4 * kk;
+    std::vector<double> L(2 * kk, 0.0);
+    std::copy(L_hi, L_hi + kk, L.begin());
+    if (L_lo) std::copy(L_lo, L_lo + kk, L.begin() + kk);
+    double *d_L = nullptr, *d_F = nullptr;
+    int *d_mask = nullptr;
+    dd *d_scr = nullptr;
+    auto cleanup = [&]() {
+        if (d_L) (void)hipFree(d_L);
+        if (d_F) (void)hipFree(d_F);
+        if (d_mask) (void)hipFree(d_mask);
+        if (d_scr) (void)hipFree(d_scr);
+    };
+    if ((rc = dev_upload(h, &d_L, L.data(), L.size())) || (rc = dev_alloc(h, &d_F, (size_t)C * E * kk))) { cleanup(); return rc; }
+    if (edge_mask && (rc = dev_upload(h, &d_mask, edge_mask, (size_t)E))) { cleanup(); return rc; }
+    const size_t lds_bytes = 4 * n2 * sizeof(dd);
+    const int use_lds = lds_bytes <= 64 * 1024;
+    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * 4 * n2))) { cleanup(); return rc; }
+    const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
+    hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+                       k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
+                       d_scr, use_lds, d_L, coef_mode, d_mask, d_F);
+    if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_edge_expect: Frechet kernel launch failed"; return PLK_E_DEVICE; }
+    rc = run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out, d_F, 0);
+    cleanup();
+    return rc;
+}
+
+extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode, double *F_out)
+{
+    if (!h || !L_hi || !F_out) return PLK_E_ARG;
+    if (h->k == 0) { h->err = "plk_get_frechet_matrices: model must be set"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    const int k = h->k, C = h->C, E = h->E;
+    if (E == 0) return PLK_OK;
+    const size_t kk = (size_t)k * k, n2 = 4 * kk;
+    std::vector<double> L(2 * kk, 0.0);
+    std::copy(L_hi, L_hi + kk, L.begin());
+    if (L_lo) std::copy(L_lo, L_lo + kk, L.begin() + kk);
+    double *d_L = nullptr, *d_F = nullptr;
+    dd *d_scr = nullptr;
+    auto cleanup = [&]() {
+        if (d_L) (void)hipFree(d_L);
+        if (d_F) (void)hipFree(d_F);
+        if (d_scr) (void)hipFree(d_scr);
+    };
+    if ((rc = dev_upload(h, &d_L, L.data(), L.size())) || (rc = dev_alloc(h, &d_F, (size_t)C * E * kk))) { cleanup(); return rc; }
+    const size_t lds_bytes = 4 * n2 * sizeof(dd);
+    const int use_lds = lds_bytes <= 64 * 1024;
+    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * 4 * n2))) { cleanup(); return rc; }
+    const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
+    hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+                       k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
+                       d_scr, use_lds, d_L, coef_mode, (const int *)nullptr, d_F);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(F_out, d_F, (size_t)C * E * kk * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) { h->err = std::string("plk_get_frechet_matrices: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+    return PLK_OK;
 }
 
 extern "C" int plk_marginal(plk_engine *h, const int *node_mask, double *site_out, double *sums_out)

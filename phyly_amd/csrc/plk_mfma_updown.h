@@ -19,6 +19,7 @@
 struct MUpArgs {
     long S, Spad, s0, n;          /* chunk [s0, s0+n) of the pattern extent */
     int N, E, k, kk4, C, nchar, ntips, root_mode;
+    int dzero;                    /* 1: edge-form matrices have zero row sums (dP) */
     const int *indptr, *indices, *preorder;
     const int *node_has_data;
     const int *edge_tip;          /* E: tip slot of a leaf edge, -1 for internal edges */
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
                         mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, x);
                         mf_stage(lds_frag, a.fragD + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                         mf_matvec<T>(lds_frag, a.kk4, lane, x, y);
-                        if (mf_is_const<R>(x, g, a.k, x0)) {
+                        if (a.dzero && mf_is_const<R>(x, g, a.k, x0)) {
 #pragma unroll
                             for (int r = 0; r < R; r++) y[r] = 0.0;
                         }
@@ -309,7 +310,7 @@ __global__ void k_build_frag_edges(int k, int T, int kk4, int transpose, const d
  * (rows of dP sum to zero; the reference's exact shortcut, src/util.c:338-345) */
 __global__ void k_build_dtip_dist(int k, int R, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
                                   const double *__restrict__ dP, const double *__restrict__ defs, int Kpad,
-                                  double *__restrict__ dtip)
+                                  double *__restrict__ dtip, int dzero)
 {
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
@@ -323,7 +324,7 @@ __global__ void k_build_dtip_dist(int k, int R, int E, int ntips, int nchar, con
         if (i < k && e >= 0) {
             bool constant = true;
             for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
-            if (!constant) {
+            if (!(constant && dzero)) {
                 const double *row = dP + ((size_t)c * E + e) * k * k + (size_t)i * k;
                 dd acc = dd_make(0.0, 0.0);
                 for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));

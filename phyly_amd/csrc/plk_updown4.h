@@ -20,6 +20,7 @@
 struct Up4Args {
     long S, Spad, s0, n;
     int N, E, C, nchar, ntips, root_mode;
+    int dzero;                     /* 1: edge-form matrices have zero row sums (dP) */
     const int *indptr, *indices, *preorder;
     const int *node_has_data, *edge_tip, *edge_int, *node_int;
     const double *P, *dP;          /* [C][E][4][4] row-major */
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                     else {
                         const v4 x = ld4(a.LN + (((size_t)nint[b] * a.C + c) * n + slc) * 4);
                         y = mv4(dPm + ((size_t)c * a.E + idx) * 16, x);
-                        if (const4(x)) y = v4{0.0, 0.0, 0.0, 0.0};     /* rows of dP sum to zero (src/util.c:338-345) */
+                        if (a.dzero && const4(x)) y = v4{0.0, 0.0, 0.0, 0.0};     /* rows of dP sum to zero (src/util.c:338-345) */
                     }
                     const double d = fma(fe.d, y.d, fma(fe.c, y.c, fma(fe.b, y.b, fe.a * y.a)));
                     dsum = fma(pc, d, dsum);
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
 
 /* dtip[c][t][code][i] = (dP_e defs[code])[i] (zero for constant definition rows) */
 __global__ void k_build_dtip4(int E, int ntips, int nchar, const int *__restrict__ tip_edge,
-                              const double *__restrict__ dP, const double *__restrict__ defs, double *__restrict__ dtip)
+                              const double *__restrict__ dP, const double *__restrict__ defs, double *__restrict__ dtip,
+                              int dzero)
 {
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
@@ -221,7 +223,7 @@ __global__ void k_build_dtip4(int E, int ntips, int nchar, const int *__restrict
         const int code = idx >> 2, i = idx & 3;
         const double *d = defs + code * 4;
         double out = 0.0;
-        if (e >= 0 && !(d[0] == d[1] && d[0] == d[2] && d[0] == d[3])) {
+        if (e >= 0 && !(dzero && d[0] == d[1] && d[0] == d[2] && d[0] == d[3])) {
             const double *row = dP + ((size_t)c * E + e) * 16 + i * 4;
             dd acc = dd_make(0.0, 0.0);
             for (int j = 0; j < 4; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));

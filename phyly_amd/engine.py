@@ -19,6 +19,7 @@ HOST, DEVICE = 0, 1
 ROOT_NONE, ROOT_CUSTOM, ROOT_UNIFORM, ROOT_EQUILIBRIUM = 1, 2, 3, 4
 INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS = range(5)
 OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA = 0, 1, 2, 3, 4
+COEF_PRIOR, COEF_PRIOR_RATE_EDGE, COEF_PRIOR_RATE = 0, 1, 2
 
 _lib = None
 
@@ -53,6 +54,8 @@ def load_library():
     lib.plk_ll.argtypes = [vp, vp, ci, vp]
     lib.plk_deriv.argtypes = [vp, vp, vp, vp]
     lib.plk_marginal.argtypes = [vp, vp, vp, vp]
+    lib.plk_edge_expect.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+    lib.plk_get_frechet_matrices.argtypes = [vp, vp, vp, ci, vp]
     lib.plk_get_transition_matrices.argtypes = [vp, vp]
     lib.plk_get_info.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.plk_set_option.argtypes = [vp, ci, cl]
@@ -177,6 +180,23 @@ class Engine:
         sums = np.zeros((self.N, self.k, 2)) if want_sums else None
         self._check(self._lib.plk_marginal(self._h, _ptr(mask), _ptr(out), _ptr(sums)))
         return out, sums
+
+    def edge_expect(self, L, coef_mode, L_lo=None, edge_mask=None, per_site=True, want_sums=True):
+        """conditional edge expectations for the direction matrix L (see include/plk.h:plk_edge_expect)"""
+        mask = _i32(edge_mask) if edge_mask is not None else None
+        L = _f64(L)
+        L_lo = _f64(L_lo) if L_lo is not None else None
+        out = np.zeros((self.S, self.E)) if per_site else None
+        sums = np.zeros((self.E, 2)) if want_sums else None
+        self._check(self._lib.plk_edge_expect(self._h, _ptr(L), _ptr(L_lo), int(coef_mode), _ptr(mask), _ptr(out), _ptr(sums)))
+        return out, sums
+
+    def frechet_matrices(self, L, coef_mode, L_lo=None):
+        F = np.zeros((self.C, self.E, self.k, self.k))
+        L = _f64(L)
+        L_lo = _f64(L_lo) if L_lo is not None else None
+        self._check(self._lib.plk_get_frechet_matrices(self._h, _ptr(L), _ptr(L_lo), int(coef_mode), _ptr(F)))
+        return F
 
     def transition_matrices(self):
         P = np.empty((self.C, self.E, self.k, self.k))

@@ -36,7 +36,8 @@ def validate():
 
 
 def _oracle_accepts(oracle, obj, kind="ll"):
-    fn = {"ll": oracle.run_ll, "deriv": oracle.run_deriv, "marginal": oracle.run_marginal}[kind]
+    fn = {"ll": oracle.run_ll, "deriv": oracle.run_deriv, "marginal": oracle.run_marginal,
+          "dwell": oracle.run_dwell, "trans": oracle.run_trans, "em_update": oracle.run_em_update}[kind]
     try:
         fn(copy.deepcopy(obj))
         return True
@@ -246,6 +247,51 @@ def test_deriv_and_marginal_reductions(validate, oracle):
     assert validate(y, "marginal") != 0 and not _oracle_accepts(oracle, y, "marginal")
     x["edge_reduction"] = {"selection": [3]}           # only 3 edges
     assert validate(x, "deriv") != 0 and not _oracle_accepts(oracle, x, "deriv")
+
+
+def test_dwell_trans_em_reductions(validate, oracle):
+    """src/arbplfdwell.c:507-566, src/arbplftrans.c:553-614 (pair selection: src/parsereduction.c:205-392),
+    src/arbplfem.c:505-545 + :572-577 (site aggregation required)"""
+    def both(x, kind, ok):
+        assert (validate(x, kind) == 0) == ok, (kind, x)
+        assert _oracle_accepts(oracle, x, kind) == ok, (kind, x)
+    x = copy.deepcopy(GOOD)
+    x.pop("site_reduction", None)
+    both(x, "dwell", True)
+    both(x, "trans", True)
+    both(x, "em_update", False)                         # needs a site aggregation
+    x["site_reduction"] = {"aggregation": "sum"}
+    both(x, "em_update", True)
+    x["edge_reduction"] = {"aggregation": "sum"}
+    both(x, "em_update", False)                         # edge_reduction is unknown to em-update
+    both(x, "dwell", True)
+    x["state_reduction"] = {"selection": [0, 2, 2], "aggregation": [1, 2, -0.5]}
+    both(x, "dwell", True)
+    both(x, "trans", False)                             # state_reduction is unknown to arbplf-trans
+    del x["state_reduction"]
+    for tr, ok in (({"selection": [[0, 1], [2, 0]]}, True),
+                   ({"selection": [[0, 1], [2, 0]], "aggregation": [0.5, 2]}, True),
+                   ({"selection": [[0, 1]], "aggregation": "only"}, True),
+                   ({"selection": [[0, 1], [1, 0]], "aggregation": "only"}, False),
+                   ({"selection": [[1, 1]]}, True),                      # a diagonal pair is accepted
+                   ({"selection": [[0, 3]]}, False),                     # only 3 states
+                   ({"selection": [[0, -1]]}, False),
+                   ({"selection": [[0, 1, 2]]}, False),
+                   ({"selection": [[0, 1.0]]}, False),
+                   ({"selection": [0, 1]}, False),
+                   ({"selection": [[0, 1]], "aggregation": [1, 2]}, False),
+                   ({"aggregation": "sum"}, True),
+                   ({"aggregation": "avg"}, True),
+                   ({"aggregation": "only"}, False),                     # no selection: only sum / avg
+                   ({"aggregation": [1, 2, 3, 4, 5, 6]}, False),
+                   ({}, True),
+                   ({"selection": None}, True),                          # null counts as absent
+                   ({"selection": [], "aggregation": "sum"}, True),
+                   ({"selektion": []}, False)):
+        y = copy.deepcopy(x)
+        y["trans_reduction"] = tr
+        both(y, "trans", ok)
+        assert validate(y, "dwell") != 0
 
 
 @pytest.mark.parametrize("text", [
