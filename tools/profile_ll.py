@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--sites", type=int, default=2_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
-    ap.add_argument("--what", choices=["ll", "deriv", "marginal"], default="ll")
+    ap.add_argument("--what", choices=["ll", "deriv", "marginal", "dwell", "em"], default="ll")
     ap.add_argument("--fused-ns", type=int, default=0)
     args = ap.parse_args()
     from phyly_amd import synth, engine as E
@@ -45,6 +45,16 @@ def main():
             extra = "kernel %.3f ms" % (eng.info(E.INFO_LL_KERNEL_NS) * 1e-6)
         elif args.what == "deriv":
             _, s = eng.deriv(per_site=False)
+            extra = ""
+        elif args.what == "dwell":
+            # one state-aggregated dwell query (site-summed): Frechet build + down/up pass
+            _, s = eng.edge_expect(np.diag(np.arange(1.0, wl.k + 1)), E.COEF_PRIOR, per_site=False)
+            extra = ""
+        elif args.what == "em":
+            # one em-update: two edge-expectation passes (transitions, exit-rate dwell)
+            Qn = wl.prepare()["Qn"]
+            _, t = eng.edge_expect(Qn * (1 - np.eye(wl.k)), E.COEF_PRIOR_RATE, per_site=False)
+            _, d = eng.edge_expect(-np.diag(np.diag(Qn)), E.COEF_PRIOR_RATE, per_site=False)
             extra = ""
         else:
             _, s = eng.marginal(per_site=False)
