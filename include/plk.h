@@ -154,6 +154,21 @@ int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int c
 int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
                              double *F_out);
 
+/*
+ * Fit the edge rate coefficients by maximum likelihood with the patterns, weights and tree resident on the
+ * device.  The reference has no driver for this: its old-examples/opt.py and
+ * old-examples/gell_dna_opt.py drive scipy's L-BFGS-B with arbplf_ll / arbplf_deriv through the Python API,
+ * and test_scripts/test_em_monotonicity.py:95-130 iterates arbplf_em_update; this entry point is that loop.
+ * method PLK_FIT_EM: r_e <- r_e * E[transitions on e] / E[rate-weighted dwell on e] (src/arbplfem.c:397-503);
+ * method PLK_FIT_LBFGS: L-BFGS on log r_e, gradient from the deriv pass.  Edges with rate 0 or outside
+ * edge_mask stay fixed.  Stops after max_iter iterations or when the gain in the weighted log likelihood is
+ * <= ftol * max(1, |ll|).  rates_inout: E doubles, CSR order (also left set in the engine);
+ * ll_trace: NULL or max_iter + 1 doubles (ll before the first and after every iteration).
+ */
+enum { PLK_FIT_EM = 0, PLK_FIT_LBFGS = 1 };
+int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, double ftol, const int *edge_mask,
+                       double *rates_inout, double *ll_trace, int *iters_out, long *evals_out);
+
 /* Introspection for tests and profiling. */
 int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
 int plk_get_info(plk_engine *h, int what, long *out);

@@ -1993,3 +1993,156 @@ extern "C" int plk_marginal(plk_engine *h, const int *node_mask, double *site_ou
     if (!h) return PLK_E_ARG;
     return run_updown(h, false, true, nullptr, node_mask, site_out, sums_out);
 }
+
+/* ====================================================================== */
+/* Edge-rate optimisation with the patterns resident      */
+/* ====================================================================== */
+
+static int fit_objective(plk_engine *h, const std::vector<double> &rates, long double *ll_out)
+{
+    int rc;
+    if ((rc = plk_update_edge_rates(h, rates.data()))) return rc;
+    double s[2] = {0.0, 0.0};
+    if ((rc = plk_ll(h, nullptr, PLK_HOST, s))) return rc;
+    *ll_out = (long double)s[0] + (long double)s[1];
+    return PLK_OK;
+}
+
+/*
+ * Maximise sum_s w_s ll_s over the edge rate coefficients.  The reference has no driver for this; its
+ * old-examples/opt.py and old-examples/gell_dna_opt.py run scipy's L-BFGS-B over arbplf_ll / arbplf_deriv
+ * through the Python API, and test_scripts/test_em_monotonicity.py iterates arbplf_em_update.  Here the loop
+ * runs next to the device: patterns, weights and the tree stay resident, an iteration re-runs K1 and the
+ * traversal kernels only.
+ *   PLK_FIT_EM     r_e <- r_e * E[transitions on e] / E[rate-weighted dwell on e]   (src/arbplfem.c:397-503)
+ *   PLK_FIT_LBFGS  L-BFGS (8 pairs, Armijo backtracking) on log r_e with the gradient r_e * d ll / d r_e
+ */
+extern "C" int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, double ftol, const int *edge_mask,
+                                  double *rates_inout, double *ll_trace, int *iters_out, long *evals_out)
+{
+    if (!h || !rates_inout) return PLK_E_ARG;
+    if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_fit_edge_rates: tree, model and patterns must be set"; return PLK_E_ARG; }
+    if (method != PLK_FIT_EM && method != PLK_FIT_LBFGS) { h->err = "plk_fit_edge_rates: unknown method"; return PLK_E_ARG; }
+    const int E = h->E, k = h->k;
+    const size_t kk = (size_t)k * k;
+    int rc;
+    long evals = 0;
+    std::vector<double> rates(rates_inout, rates_inout + E);
+    for (int e = 0; e < E; e++)
+        if (!(rates[e] >= 0.0) || !std::isfinite(rates[e])) { h->err = "plk_fit_edge_rates: rates must be finite and non-negative"; return PLK_E_ARG; }
+    std::vector<int> free_e;
+    for (int e = 0; e < E; e++) if ((!edge_mask || edge_mask[e]) && rates[e] > 0.0) free_e.push_back(e);
+    std::vector<int> mask(std::max(E, 1), 0);
+    for (int e : free_e) mask[e] = 1;
+    long double ll = 0;
+    if ((rc = fit_objective(h, rates, &ll))) return rc;
+    evals++;
+    if (ll_trace) ll_trace[0] = (double)ll;
+    int it = 0;
+    if (!std::isfinite((double)ll)) { h->err = "plk_fit_edge_rates: the initial log likelihood is not finite"; return PLK_E_ARG; }
+
+    if (method == PLK_FIT_EM) {
+        std::vector<double> Ld(2 * kk, 0.0), Lt(2 * kk, 0.0), dw((size_t)2 * E + 2), tr((size_t)2 * E + 2);
+        for (int i = 0; i < k; i++)
+            for (int j = 0; j < k; j++) {
+                const size_t q = (size_t)i * k + j;
+                if (i == j) { Ld[q] = -h->Qn[q]; Ld[kk + q] = -h->Qn[kk + q]; }
+                else { Lt[q] = h->Qn[q]; Lt[kk + q] = h->Qn[kk + q]; }
+            }
+        for (; it < max_iter && !free_e.empty(); ) {
+            if ((rc = plk_edge_expect(h, Ld.data(), Ld.data() + kk, PLK_COEF_PRIOR_RATE, mask.data(), nullptr, dw.data()))) return rc;
+            if ((rc = plk_edge_expect(h, Lt.data(), Lt.data() + kk, PLK_COEF_PRIOR_RATE, mask.data(), nullptr, tr.data()))) return rc;
+            for (int e : free_e) {
+                const long double t = (long double)tr[2 * e] + (long double)tr[2 * e + 1];
+                const long double d = (long double)dw[2 * e] + (long double)dw[2 * e + 1];
+                const double v = t == 0 ? 0.0 : (double)(t / d * (long double)rates[e]);
+                if (!std::isfinite(v) || v < 0) { h->err = "plk_fit_edge_rates: EM update is not finite"; return PLK_E_DEVICE; }
+                rates[e] = v;
+            }
+            long double ll_new = 0;
+            if ((rc = fit_objective(h, rates, &ll_new))) return rc;
+            evals++;
+            it++;
+            if (ll_trace) ll_trace[it] = (double)ll_new;
+            const long double gain = ll_new - ll;
+            ll = ll_new;
+            if (fabsl(gain) <= (long double)ftol * std::max<long double>(1.0L, fabsl(ll))) break;
+        }
+    } else {
+        const int n = (int)free_e.size(), M = 8;
+        std::vector<double> x(n), g(n), xn(n), gn(n), d(n), sums((size_t)2 * E + 2);
+        std::vector<std::vector<double>> Sh, Yh;
+        std::vector<double> rho;
+        auto gradient = [&](const std::vector<double> &r, std::vector<double> &out) -> int {
+            /* rates are already current on the device (set by the accepted objective evaluation) */
+            int rc2 = plk_deriv(h, mask.data(), nullptr, sums.data());
+            if (rc2) return rc2;
+            for (int i = 0; i < n; i++) {
+                const int e = free_e[i];
+                out[i] = -(double)(((long double)sums[2 * e] + (long double)sums[2 * e + 1]) * (long double)r[e]);
+            }
+            return PLK_OK;
+        };
+        for (int i = 0; i < n; i++) x[i] = std::log(rates[free_e[i]]);
+        if (n > 0 && (rc = gradient(rates, g))) return rc;
+        double f = -(double)ll;
+        for (; it < max_iter && n > 0; ) {
+            /* two-loop recursion */
+            d = g;
+            const int hs = (int)Sh.size();
+            std::vector<double> alpha(hs);
+            for (int j = hs - 1; j >= 0; j--) {
+                double a = 0; for (int i = 0; i < n; i++) a += Sh[j][i] * d[i];
+                a *= rho[j]; alpha[j] = a;
+                for (int i = 0; i < n; i++) d[i] -= a * Yh[j][i];
+            }
+            if (hs > 0) {
+                double sy = 0, yy = 0;
+                for (int i = 0; i < n; i++) { sy += Sh[hs - 1][i] * Yh[hs - 1][i]; yy += Yh[hs - 1][i] * Yh[hs - 1][i]; }
+                const double gam = sy / yy;
+                for (int i = 0; i < n; i++) d[i] *= gam;
+            }
+            for (int j = 0; j < hs; j++) {
+                double b = 0; for (int i = 0; i < n; i++) b += Yh[j][i] * d[i];
+                b *= rho[j];
+                for (int i = 0; i < n; i++) d[i] += Sh[j][i] * (alpha[j] - b);
+            }
+            double gd = 0, gnorm = 0, dmax = 0;
+            for (int i = 0; i < n; i++) { d[i] = -d[i]; gd += g[i] * d[i]; gnorm = std::max(gnorm, std::fabs(g[i])); }
+            if (!(gd < 0)) { Sh.clear(); Yh.clear(); rho.clear(); gd = 0; for (int i = 0; i < n; i++) { d[i] = -g[i]; gd += g[i] * d[i]; } }
+            if (gnorm == 0) break;
+            for (int i = 0; i < n; i++) dmax = std::max(dmax, std::fabs(d[i]));
+            double t = Sh.empty() ? std::min(1.0, 1.0 / dmax) : 1.0;
+            if (t * dmax > 5.0) t = 5.0 / dmax;                 /* at most a factor e^5 per step on any rate */
+            bool ok = false;
+            long double ll_new = 0;
+            std::vector<double> rn = rates;
+            for (int ls = 0; ls < 40; ls++, t *= 0.5) {
+                for (int i = 0; i < n; i++) { xn[i] = x[i] + t * d[i]; rn[free_e[i]] = std::exp(xn[i]); }
+                if ((rc = fit_objective(h, rn, &ll_new))) return rc;
+                evals++;
+                const double fn = -(double)ll_new;
+                if (std::isfinite(fn) && fn <= f + 1e-4 * t * gd) { ok = true; break; }
+            }
+            if (!ok) { if ((rc = plk_update_edge_rates(h, rates.data()))) return rc; break; }
+            if ((rc = gradient(rn, gn))) return rc;
+            std::vector<double> s(n), y(n);
+            double sy = 0, ss = 0, yy = 0;
+            for (int i = 0; i < n; i++) { s[i] = xn[i] - x[i]; y[i] = gn[i] - g[i]; sy += s[i] * y[i]; ss += s[i] * s[i]; yy += y[i] * y[i]; }
+            if (sy > 1e-10 * std::sqrt(ss * yy)) {
+                if ((int)Sh.size() == M) { Sh.erase(Sh.begin()); Yh.erase(Yh.begin()); rho.erase(rho.begin()); }
+                Sh.push_back(s); Yh.push_back(y); rho.push_back(1.0 / sy);
+            }
+            const double fn = -(double)ll_new, gain = f - fn;
+            x = xn; g = gn; rates = rn; f = fn; ll = ll_new;
+            it++;
+            if (ll_trace) ll_trace[it] = (double)ll;
+            if (gain <= ftol * std::max(1.0, std::fabs(f))) break;
+        }
+    }
+    if ((rc = plk_update_edge_rates(h, rates.data()))) return rc;
+    std::copy(rates.begin(), rates.end(), rates_inout);
+    if (iters_out) *iters_out = it;
+    if (evals_out) *evals_out = evals;
+    return PLK_OK;
+}

@@ -20,6 +20,7 @@ ROOT_NONE, ROOT_CUSTOM, ROOT_UNIFORM, ROOT_EQUILIBRIUM = 1, 2, 3, 4
 INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS = range(5)
 OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA = 0, 1, 2, 3, 4
 COEF_PRIOR, COEF_PRIOR_RATE_EDGE, COEF_PRIOR_RATE = 0, 1, 2
+FIT_EM, FIT_LBFGS = 0, 1
 
 _lib = None
 
@@ -56,6 +57,7 @@ def load_library():
     lib.plk_marginal.argtypes = [vp, vp, vp, vp]
     lib.plk_edge_expect.argtypes = [vp, vp, vp, ci, vp, vp, vp]
     lib.plk_get_frechet_matrices.argtypes = [vp, vp, vp, ci, vp]
+    lib.plk_fit_edge_rates.argtypes = [vp, ci, ci, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ci), ctypes.POINTER(cl)]
     lib.plk_get_transition_matrices.argtypes = [vp, vp]
     lib.plk_get_info.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.plk_set_option.argtypes = [vp, ci, cl]
@@ -197,6 +199,17 @@ class Engine:
         L_lo = _f64(L_lo) if L_lo is not None else None
         self._check(self._lib.plk_get_frechet_matrices(self._h, _ptr(L), _ptr(L_lo), int(coef_mode), _ptr(F)))
         return F
+
+    def fit_edge_rates(self, rates, method=FIT_LBFGS, max_iter=100, ftol=1e-10, edge_mask=None):
+        """maximum-likelihood edge rates with everything resident on the device
+        -> (rates, ll_trace[:iters + 1], objective evaluations); see include/plk.h:plk_fit_edge_rates"""
+        r = _f64(rates).copy()
+        mask = _i32(edge_mask) if edge_mask is not None else None
+        trace = np.zeros(int(max_iter) + 1)
+        iters, evals = ctypes.c_int(0), ctypes.c_long(0)
+        self._check(self._lib.plk_fit_edge_rates(self._h, int(method), int(max_iter), float(ftol), _ptr(mask), _ptr(r),
+                                                 _ptr(trace), ctypes.byref(iters), ctypes.byref(evals)))
+        return r, trace[:iters.value + 1].copy(), evals.value
 
     def transition_matrices(self):
         P = np.empty((self.C, self.E, self.k, self.k))

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--sites", type=int, default=2_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
-    ap.add_argument("--what", choices=["ll", "deriv", "marginal", "dwell", "em"], default="ll")
+    ap.add_argument("--what", choices=["ll", "deriv", "marginal", "dwell", "em", "fit"], default="ll")
     ap.add_argument("--fused-ns", type=int, default=0)
     args = ap.parse_args()
     from phyly_amd import synth, engine as E
@@ -49,6 +49,16 @@ def main():
         elif args.what == "dwell":
             # one state-aggregated dwell query (site-summed): Frechet build + down/up pass
             _, s = eng.edge_expect(np.diag(np.arange(1.0, wl.k + 1)), E.COEF_PRIOR, per_site=False)
+            extra = ""
+        elif args.what == "fit":
+            # device-resident L-BFGS / EM fits from perturbed rates; reports iterations per second
+            start = wl.edge_rates_csr * np.exp(np.random.default_rng(i).uniform(-0.7, 0.7, wl.E))
+            for meth, name in ((E.FIT_LBFGS, "lbfgs"), (E.FIT_EM, "em")):
+                t1 = time.perf_counter()
+                _, tr, ev = eng.fit_edge_rates(start, method=meth, max_iter=25, ftol=1e-12)
+                d1 = time.perf_counter() - t1
+                print("  %s: %d iterations, %d ll evaluations, %.1f ms/iteration, ll %.6f -> %.6f"
+                      % (name, len(tr) - 1, ev, d1 * 1e3 / max(1, len(tr) - 1), tr[0], tr[-1]), flush=True)
             extra = ""
         elif args.what == "em":
             # one em-update: two edge-expectation passes (transitions, exit-rate dwell)
