@@ -25,6 +25,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +92,7 @@ struct plk_engine {
     std::vector<int2> ops;
     std::vector<int> op_edge;            /* CSR edge per op or -1 */
     std::vector<int> tip_edge;           /* CSR edge per tip slot */
+    std::vector<char> scale_node;        /* N: node vectors rescaled here (every >= 16 accumulated edges) */
     std::vector<int> obs_nodes;          /* nodes whose codes the fused kernel stages */
     int slots_needed = 0;
     int2 *d_ops = nullptr;
@@ -1168,7 +1170,8 @@ static int build_program(plk_engine *h)
     const int N = h->N;
     const std::vector<int> &ip = h->indptr, &ix = h->indices;
     std::vector<int> need(N, 0), since(N, 0);
-    std::vector<char> scale_here(N, 0);
+    std::vector<char> &scale_here = h->scale_node;
+    scale_here.assign(N, 0);
     std::vector<std::vector<int>> ichild(N); /* internal children (CSR edge idx), sorted by need desc */
     for (int u = N - 1; u >= 0; u--) {
         const int a = h->preorder[u];
@@ -1700,17 +1703,21 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     if (nin == 0) { node_int[h->preorder[0]] = nin++; }      /* a single-node tree still has a root vector */
     std::vector<int> te = h->tip_edge;
     te.push_back(-1);
+    std::vector<int> node_scale(N, -1);
+    int nsc = 0;
+    for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr;
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_tip4, d_dtip4};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_tip4, d_dtip4};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)std::max(E, 1))) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)std::max(E, 1))) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
+        (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
         (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
     if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
@@ -1722,7 +1729,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
                        E, ntips, h->nchar, d_te, d_M, h->d_defs, d_dtip4, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -1742,13 +1749,15 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.N = N; a.E = E; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
         a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
-        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni;
+        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni; a.node_scale = d_ns;
         a.P = h->d_P; a.dP = d_M; a.tip = d_tip4; a.dtip = d_dtip4;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
         double *p = h->d_work;
-        a.EV = p; p += (size_t)nie * C * 4 * n;
         a.LN = p; p += (size_t)nin * C * 4 * n;
         a.FN = p; p += (size_t)nin * C * 4 * n;
+        a.SC = p; p += (size_t)nsc * C * n;
+        a.CW = p; p += (size_t)C * n;
+        a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * 4 * n;

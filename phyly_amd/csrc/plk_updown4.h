@@ -9,10 +9,17 @@
  * HBM roofline that bounds them:
  *   - stored vectors are interleaved [entity][category][site][4]: one lane moves its whole
  *     4-vector with two 16-byte accesses, a wavefront moves 2 KB contiguously;
- *   - only internal edges and internal nodes are stored; leaf-edge vectors P_e B_b and
- *     derivative vectors dP_e B_b are gathered by pattern code from small tables
+ *   - only the node vectors L_a and F_a of internal nodes are stored; edge vectors
+ *     Ev_e = P_e L_b are recomputed in the up pass from the L_b that the edge form needs
+ *     anyway (all children of a node are handled together, so L_b and F_a are read once);
+ *     leaf-edge vectors P_e B_b and M_e B_b are gathered by pattern code from small tables
  *     (double-double built) that live in L1/L2;
- *   - P_e, P_e^T and dP_e are wave-uniform: scalar loads, SGPR operands, no LDS.
+ *   - P_e, P_e^T and M_e (dP or a Frechet matrix) are wave-uniform: scalar loads, SGPR
+ *     operands, no LDS;
+ *   - node vectors are rescaled by exact powers of two at the nodes the traversal program
+ *     marks (every >= 16 accumulated edges); the factors are stored (SC) and re-applied to
+ *     the forward vectors, categories are combined at a common exponent (CW), so trees of
+ *     any size stay inside the double range.
  */
 #ifndef PLK_UPDOWN4_H
 #define PLK_UPDOWN4_H
@@ -28,8 +35,11 @@ struct Up4Args {
     const uint8_t *codes;
     const double *cat_prior, *root_w;
     const int *edge_mask, *node_mask;
-    double *EV, *LN, *FN;          /* [(ent*C + c)][n][4] */
-    double *LH, *DV, *MV;          /* [n], [E][n], [N][4][n] */
+    const int *node_scale;         /* N: index of the node's rescaling slot, -1 = not rescaled */
+    double *LN, *FN;               /* [(ent*C + c)][n][4] */
+    double *SC;                    /* [(slot*C + c)][n]: 2^-e applied to L_a at rescaled nodes */
+    double *CW, *XC;               /* [C][n]: 2^(X_c - Xmax); scratch: X_c and category likelihood mantissas */
+    double *LH, *DV, *MV;          /* [n] (at exponent Xmax), [E][n], [N][4][n] */
 };
 
 struct v4 { double a, b, c, d; };
@@ -70,6 +80,16 @@ __device__ static inline v4 mtv4(const PLK_AS4 double *M, const v4 &x)
 
 #define UD4_BLOCK 256
 
+/* child message: table gather for a leaf edge, P_e L_b (exact for constant L_b, src/util.c:276-283) otherwise */
+__device__ static inline v4 ud4_child_msg(const Up4Args &a, int c, int idx, int t, int code, const double *tipc,
+                                          const PLK_AS4 double *Pm, const v4 &x)
+{
+    if (t >= 0) return ld4(tipc + ((size_t)t * a.nchar + code) * 4);
+    v4 m = mv4(Pm + ((size_t)c * a.E + idx) * 16, x);
+    if (const4(x)) m = x;
+    return m;
+}
+
 __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
 {
     const long sl = (long)blockIdx.x * UD4_BLOCK + threadIdx.x;
@@ -79,13 +99,14 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
     const size_t n = (size_t)a.n;
     const PLK_AS4 int *pre = as_uniform(a.preorder), *ip = as_uniform(a.indptr), *ix = as_uniform(a.indices);
     const PLK_AS4 int *has = as_uniform(a.node_has_data), *etip = as_uniform(a.edge_tip);
-    const PLK_AS4 int *eint = as_uniform(a.edge_int), *nint = as_uniform(a.node_int);
+    const PLK_AS4 int *nint = as_uniform(a.node_int), *nsc = as_uniform(a.node_scale);
     const PLK_AS4 double *Pm = as_uniform(a.P), *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
-    double lh_total = 0.0;
+    int xmax = INT_MIN;
     for (int c = 0; c < a.C; c++) {
         const double *tipc = a.tip + (size_t)c * tabc;
         double lh_c = 0.0;
+        int X = 0;
         for (int u = a.N - 1; u >= 0; u--) {
             const int nd = pre[u];
             const int start = ip[nd], stop = ip[nd + 1];
@@ -94,17 +115,24 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
             if (has[nd]) acc = ld4(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * 4);
             for (int idx = start; idx < stop; idx++) {
                 const int b = ix[idx];
-                v4 m;
                 const int t = etip[idx];
-                if (t >= 0) {
-                    m = ld4(tipc + ((size_t)t * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * 4);
-                } else {
-                    const v4 x = ld4(a.LN + (((size_t)nint[b] * a.C + c) * n + slc) * 4);
-                    m = mv4(Pm + ((size_t)c * a.E + idx) * 16, x);
-                    if (const4(x)) m = x;          /* exact constant column (src/util.c:276-283) */
-                    if (valid) st4(a.EV + (((size_t)eint[idx] * a.C + c) * n + slc) * 4, m);
+                v4 x = v4{0.0, 0.0, 0.0, 0.0};
+                int code = 0;
+                if (t >= 0) code = a.codes[(size_t)b * a.Spad + sg];
+                else x = ld4(a.LN + (((size_t)nint[b] * a.C + c) * n + slc) * 4);
+                acc = mul4(acc, ud4_child_msg(a, c, idx, t, code, tipc, Pm, x));
+            }
+            const int slot = nsc[nd];
+            if (slot >= 0) {
+                const double mx = fmax(fmax(acc.a, acc.b), fmax(acc.c, acc.d));
+                double sc = 1.0;
+                if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                    const int e = ilogb(mx);
+                    sc = ldexp(1.0, -e);
+                    acc.a *= sc; acc.b *= sc; acc.c *= sc; acc.d *= sc;
+                    X += e;
                 }
-                acc = mul4(acc, m);
+                if (valid) a.SC[((size_t)slot * a.C + c) * n + slc] = sc;
             }
             if (valid) st4(a.LN + (((size_t)nint[nd] * a.C + c) * n + slc) * 4, acc);
             if (u == 0) {
@@ -113,9 +141,37 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
                 else lh_c = fma(rw[3], acc.d, fma(rw[2], acc.c, fma(rw[1], acc.b, rw[0] * acc.a)));
             }
         }
-        lh_total = fma(prior[c], lh_c, lh_total);
+        lh_c *= prior[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid) { a.XC[(size_t)c * n + slc] = (double)X; a.CW[(size_t)c * n + slc] = lh_c; }
     }
-    if (valid) a.LH[sl] = lh_total;
+    /* combine the categories at the largest exponent: LH = sum_c prior_c lh_c 2^(X_c - Xmax) */
+    if (xmax == INT_MIN) xmax = 0;
+    double lh_total = 0.0;
+    if (valid) {
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + slc] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + slc], w, lh_total);
+            a.CW[(size_t)c * n + slc] = w;
+        }
+        a.LH[sl] = lh_total;
+    }
+}
+
+/* per-child state of the up pass */
+struct Ud4Child {
+    int idx, b, t, code;
+    bool want_d, want_m, want_f;
+};
+
+__device__ static inline Ud4Child ud4_child(const Up4Args &a, int idx, long sg)
+{
+    Ud4Child ch;
+    ch.idx = idx;
+    ch.b = as_uniform(a.indices)[idx];
+    ch.t = as_uniform(a.edge_tip)[idx];
+    ch.code = ch.t >= 0 ? a.codes[(size_t)ch.b * a.Spad + sg] : 0;
+    return ch;
 }
 
 template <bool DERIV, bool MARG>
@@ -128,21 +184,23 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
     const size_t n = (size_t)a.n;
     const PLK_AS4 int *pre = as_uniform(a.preorder), *ip = as_uniform(a.indptr), *ix = as_uniform(a.indices);
     const PLK_AS4 int *has = as_uniform(a.node_has_data), *etip = as_uniform(a.edge_tip);
-    const PLK_AS4 int *eint = as_uniform(a.edge_int), *nint = as_uniform(a.node_int);
-    const PLK_AS4 double *Pm = as_uniform(a.P), *dPm = as_uniform(a.dP);
+    const PLK_AS4 int *nint = as_uniform(a.node_int), *nsc = as_uniform(a.node_scale);
+    const PLK_AS4 double *Pm = as_uniform(a.P), *Mm = as_uniform(a.dP);
     const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
     const double inv = 1.0 / a.LH[slc];
     const int root = pre[0];
     const v4 w = v4{rw[0], rw[1], rw[2], rw[3]};
+    const v4 zero = v4{0.0, 0.0, 0.0, 0.0};
 
     {   /* root: forward vector = root prior weights; its marginal */
-        v4 macc = v4{0.0, 0.0, 0.0, 0.0};
+        v4 macc = zero;
         for (int c = 0; c < a.C; c++) {
             if (valid) st4(a.FN + (((size_t)nint[root] * a.C + c) * n + slc) * 4, w);
             if (MARG) {
+                /* L_root carries every rescaling; F_root none */
                 const v4 l = ld4(a.LN + (((size_t)nint[root] * a.C + c) * n + slc) * 4);
-                const double pc = prior[c];
+                const double pc = prior[c] * a.CW[(size_t)c * n + slc];
                 macc.a = fma(pc * w.a, l.a, macc.a); macc.b = fma(pc * w.b, l.b, macc.b);
                 macc.c = fma(pc * w.c, l.c, macc.c); macc.d = fma(pc * w.d, l.d, macc.d);
             }
@@ -156,56 +214,130 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
     for (int u = 0; u < a.N; u++) {
         const int nd = pre[u];
         const int start = ip[nd], stop = ip[nd + 1];
-        if (start == stop) continue;
+        const int deg = stop - start;
+        if (deg == 0) continue;
         const bool hd = has[nd] != 0;
         const int chn = hd ? a.codes[(size_t)nd * a.Spad + sg] : 0;
-        for (int idx = start; idx < stop; idx++) {
-            const int b = ix[idx];
-            const int tb = etip[idx];
-            const bool b_leaf = tb >= 0;
-            const bool want_d = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[idx]);
-            const bool want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[b]);
-            const bool want_f = !b_leaf || want_m;
-            if (!want_d && !want_f) continue;
-            const int chb = b_leaf ? a.codes[(size_t)b * a.Spad + sg] : 0;
-            double dsum = 0.0;
-            v4 macc = v4{0.0, 0.0, 0.0, 0.0};
+        const int slot = nsc[nd];
+        const double *fn_nd = a.FN + ((size_t)nint[nd] * a.C) * n * 4;
+
+        if (deg <= 2) {
+            /* both children together: F_a, L_b0, L_b1 are read once, nothing is recomputed */
+            Ud4Child c0 = ud4_child(a, start, sg), c1 = ud4_child(a, deg == 2 ? start + 1 : start, sg);
+            c0.want_d = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[c0.idx]);
+            c1.want_d = DERIV && deg == 2 && (!a.edge_mask || as_uniform(a.edge_mask)[c1.idx]);
+            c0.want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[c0.b]);
+            c1.want_m = MARG && deg == 2 && (!a.node_mask || as_uniform(a.node_mask)[c1.b]);
+            c0.want_f = c0.t < 0 || c0.want_m;
+            c1.want_f = deg == 2 && (c1.t < 0 || c1.want_m);
+            double d0 = 0.0, d1 = 0.0;
+            v4 m0 = zero, m1 = zero;
             for (int c = 0; c < a.C; c++) {
                 const double *tipc = a.tip + (size_t)c * tabc;
-                v4 fe = ld4(a.FN + (((size_t)nint[nd] * a.C + c) * n + slc) * 4);
+                v4 g = ld4(fn_nd + ((size_t)c * n + slc) * 4);
+                if (hd) g = mul4(g, ld4(tipc + ((size_t)a.ntips * a.nchar + chn) * 4));
+                if (slot >= 0) {
+                    const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+                    g.a *= sc; g.b *= sc; g.c *= sc; g.d *= sc;
+                }
+                const double pc = prior[c] * a.CW[(size_t)c * n + slc];
+                v4 x0 = zero, x1 = zero;
+                if (c0.t < 0) x0 = ld4(a.LN + (((size_t)nint[c0.b] * a.C + c) * n + slc) * 4);
+                if (deg == 2 && c1.t < 0) x1 = ld4(a.LN + (((size_t)nint[c1.b] * a.C + c) * n + slc) * 4);
+                v4 fe0 = g, fe1 = g;
+                if (deg == 2) {
+                    fe0 = mul4(g, ud4_child_msg(a, c, c1.idx, c1.t, c1.code, tipc, Pm, x1));
+                    fe1 = mul4(g, ud4_child_msg(a, c, c0.idx, c0.t, c0.code, tipc, Pm, x0));
+                }
+#define UD4_EDGE(CH, FE, X, DS, MS)                                                                         \
+                if (CH.want_d) {                                                                            \
+                    v4 y;                                                                                   \
+                    if (CH.t >= 0) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)CH.t * a.nchar + CH.code) * 4); \
+                    else {                                                                                  \
+                        y = mv4(Mm + ((size_t)c * a.E + CH.idx) * 16, X);                                   \
+                        if (a.dzero && const4(X)) y = zero;      /* rows of dP sum to zero (src/util.c:338-345) */ \
+                    }                                                                                       \
+                    DS = fma(pc, fma(FE.d, y.d, fma(FE.c, y.c, fma(FE.b, y.b, FE.a * y.a))), DS);           \
+                }                                                                                           \
+                if (CH.want_f) {                                                                            \
+                    const v4 fb = mtv4(Pm + ((size_t)c * a.E + CH.idx) * 16, FE);                           \
+                    if (CH.t < 0 && valid) st4(a.FN + (((size_t)nint[CH.b] * a.C + c) * n + slc) * 4, fb);  \
+                    if (CH.want_m) {                                                                        \
+                        const v4 lb = CH.t >= 0 ? ld4(tipc + ((size_t)a.ntips * a.nchar + CH.code) * 4) : X; \
+                        MS.a = fma(pc * fb.a, lb.a, MS.a); MS.b = fma(pc * fb.b, lb.b, MS.b);               \
+                        MS.c = fma(pc * fb.c, lb.c, MS.c); MS.d = fma(pc * fb.d, lb.d, MS.d);               \
+                    }                                                                                       \
+                }
+                UD4_EDGE(c0, fe0, x0, d0, m0)
+                if (deg == 2) { UD4_EDGE(c1, fe1, x1, d1, m1) }
+#undef UD4_EDGE
+            }
+            if (valid) {
+                if (c0.want_d) a.DV[(size_t)c0.idx * n + sl] = d0 * inv;
+                if (c1.want_d) a.DV[(size_t)c1.idx * n + sl] = d1 * inv;
+                if (c0.want_m) {
+                    double *mv = a.MV + (size_t)c0.b * 4 * n + sl;
+                    mv[0] = m0.a * inv; mv[n] = m0.b * inv; mv[2 * n] = m0.c * inv; mv[3 * n] = m0.d * inv;
+                }
+                if (c1.want_m) {
+                    double *mv = a.MV + (size_t)c1.b * 4 * n + sl;
+                    mv[0] = m1.a * inv; mv[n] = m1.b * inv; mv[2 * n] = m1.c * inv; mv[3 * n] = m1.d * inv;
+                }
+            }
+            continue;
+        }
+
+        /* three or more children (e.g. an unrooted tree's root): one edge at a time, sibling messages recomputed */
+        for (int idx = start; idx < stop; idx++) {
+            Ud4Child ch = ud4_child(a, idx, sg);
+            ch.want_d = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[idx]);
+            ch.want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[ch.b]);
+            ch.want_f = ch.t < 0 || ch.want_m;
+            if (!ch.want_d && !ch.want_f) continue;
+            double dsum = 0.0;
+            v4 macc = zero;
+            for (int c = 0; c < a.C; c++) {
+                const double *tipc = a.tip + (size_t)c * tabc;
+                v4 fe = ld4(fn_nd + ((size_t)c * n + slc) * 4);
                 if (hd) fe = mul4(fe, ld4(tipc + ((size_t)a.ntips * a.nchar + chn) * 4));
+                if (slot >= 0) {
+                    const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+                    fe.a *= sc; fe.b *= sc; fe.c *= sc; fe.d *= sc;
+                }
                 for (int idx2 = start; idx2 < stop; idx2++) {
                     if (idx2 == idx) continue;
-                    const int t2 = etip[idx2];
-                    if (t2 >= 0) fe = mul4(fe, ld4(tipc + ((size_t)t2 * a.nchar + a.codes[(size_t)ix[idx2] * a.Spad + sg]) * 4));
-                    else fe = mul4(fe, ld4(a.EV + (((size_t)eint[idx2] * a.C + c) * n + slc) * 4));
+                    const int t2 = etip[idx2], b2 = ix[idx2];
+                    v4 x2 = zero;
+                    int code2 = 0;
+                    if (t2 >= 0) code2 = a.codes[(size_t)b2 * a.Spad + sg];
+                    else x2 = ld4(a.LN + (((size_t)nint[b2] * a.C + c) * n + slc) * 4);
+                    fe = mul4(fe, ud4_child_msg(a, c, idx2, t2, code2, tipc, Pm, x2));
                 }
-                const double pc = prior[c];
-                if (want_d) {
+                const double pc = prior[c] * a.CW[(size_t)c * n + slc];
+                v4 x = zero;
+                if (ch.t < 0) x = ld4(a.LN + (((size_t)nint[ch.b] * a.C + c) * n + slc) * 4);
+                if (ch.want_d) {
                     v4 y;
-                    if (b_leaf) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)tb * a.nchar + chb) * 4);
+                    if (ch.t >= 0) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)ch.t * a.nchar + ch.code) * 4);
                     else {
-                        const v4 x = ld4(a.LN + (((size_t)nint[b] * a.C + c) * n + slc) * 4);
-                        y = mv4(dPm + ((size_t)c * a.E + idx) * 16, x);
-                        if (a.dzero && const4(x)) y = v4{0.0, 0.0, 0.0, 0.0};     /* rows of dP sum to zero (src/util.c:338-345) */
+                        y = mv4(Mm + ((size_t)c * a.E + idx) * 16, x);
+                        if (a.dzero && const4(x)) y = zero;
                     }
-                    const double d = fma(fe.d, y.d, fma(fe.c, y.c, fma(fe.b, y.b, fe.a * y.a)));
-                    dsum = fma(pc, d, dsum);
+                    dsum = fma(pc, fma(fe.d, y.d, fma(fe.c, y.c, fma(fe.b, y.b, fe.a * y.a))), dsum);
                 }
-                if (want_f) {
+                if (ch.want_f) {
                     const v4 fb = mtv4(Pm + ((size_t)c * a.E + idx) * 16, fe);
-                    if (!b_leaf && valid) st4(a.FN + (((size_t)nint[b] * a.C + c) * n + slc) * 4, fb);
-                    if (want_m) {
-                        const v4 lb = b_leaf ? ld4(tipc + ((size_t)a.ntips * a.nchar + chb) * 4)
-                                             : ld4(a.LN + (((size_t)nint[b] * a.C + c) * n + slc) * 4);
+                    if (ch.t < 0 && valid) st4(a.FN + (((size_t)nint[ch.b] * a.C + c) * n + slc) * 4, fb);
+                    if (ch.want_m) {
+                        const v4 lb = ch.t >= 0 ? ld4(tipc + ((size_t)a.ntips * a.nchar + ch.code) * 4) : x;
                         macc.a = fma(pc * fb.a, lb.a, macc.a); macc.b = fma(pc * fb.b, lb.b, macc.b);
                         macc.c = fma(pc * fb.c, lb.c, macc.c); macc.d = fma(pc * fb.d, lb.d, macc.d);
                     }
                 }
             }
-            if (want_d && valid) a.DV[(size_t)idx * n + sl] = dsum * inv;
-            if (want_m && valid) {
-                double *mv = a.MV + (size_t)b * 4 * n + sl;
+            if (ch.want_d && valid) a.DV[(size_t)idx * n + sl] = dsum * inv;
+            if (ch.want_m && valid) {
+                double *mv = a.MV + (size_t)ch.b * 4 * n + sl;
                 mv[0] = macc.a * inv; mv[n] = macc.b * inv; mv[2 * n] = macc.c * inv; mv[3 * n] = macc.d * inv;
             }
         }

@@ -107,3 +107,31 @@ def test_marginal_node_mask_dense(eng, oracle):
     assert np.all(got[:, ~sel] == 0.0)
     gotd, _ = eng.deriv()
     assert _row_err(gotd, wantd) <= 1e-12
+
+
+def test_deep_tree_rescaling_k4(eng, oracle):
+    """1500 taxa: site likelihoods ~ e^-2000 are far below the double range; the k = 4 down/up kernels rescale node
+    vectors by exact powers of two and combine categories at a common exponent (binary128 oracle as the checker)"""
+    from phyly_amd import synth, engine as E
+    w = synth.Workload(T=1500, k=4, tree="yule", model="gtr_g4", seed=78)
+    w.setup_engine(eng)
+    S = 48
+    codes = w.simulate(S)
+    m, ow = oracle_model(oracle, w, codes)
+    B = _dense_from_codes(w, codes)
+    eng.set_patterns_codes(codes, w.defs)
+    eng.set_site_weights(None)
+    ll, _ = eng.ll()
+    assert ll.min() < -1000.0 and np.sum(ll < -745.0) >= 10    # exp(ll) underflows for many of the sites
+    want = oracle.site_deriv(m, ow, B, precise=2)
+    got, _ = eng.deriv()
+    assert np.all(np.isfinite(got))
+    assert _row_err(got, want) <= 1e-12
+    wantm = oracle.site_marginal(m, ow, B, precise=2)
+    gotm, _ = eng.marginal()
+    assert np.max(np.abs(gotm - wantm)) <= 1e-12
+    L = np.diag([1.0, 2.0, 3.0, 4.0])
+    F = oracle.frechet(m, ow, L, 1.0, False, None, precise=2)
+    wantx = oracle.site_edge_expect(m, ow, B, F, 0, None, precise=2)
+    gotx, _ = eng.edge_expect(L, E.COEF_PRIOR)
+    assert _row_err(gotx, wantx) <= 1e-12
