@@ -44,7 +44,7 @@ def _lib():
             build()
         _LIB = ctypes.CDLL(path)
         for name in ("orc_prepare", "orc_ll", "orc_deriv", "orc_marginal", "orc_gamma_mixture",
-                     "orc_frechet", "orc_edge_expect"):
+                     "orc_frechet", "orc_edge_expect", "orc_hess"):
             getattr(_LIB, name).restype = ctypes.c_int
     return _LIB
 
@@ -834,6 +834,48 @@ def run_em_update(root):
     return {"columns": ["edge", "value"], "data": rows}
 
 
+def site_hess(m, w, B, nthreads=0, precise=2):
+    """[S][E][E] (CSR edge order) Hessians of the site log likelihoods; NaN blocks for infeasible sites."""
+    lib = _lib()
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    S = B.shape[0]
+    out = np.zeros((S, m.E, m.E))
+    P = w["Pq"] if precise == 2 else np.ascontiguousarray(w["P"])
+    Qn = w["Qq"] if precise == 2 else np.ascontiguousarray(w["Qn"])
+    lib.orc_hess(ctypes.c_int(m.N), ctypes.c_int(m.E), ctypes.c_int(m.k), ctypes.c_int(w["C"]),
+                 _iptr(m.indptr), _iptr(m.indices), _iptr(m.preorder),
+                 _dptr(P), _dptr(Qn), _dptr(w["cat_prior"]), _dptr(w["cat_rates"]),
+                 ctypes.c_int(m.root_mode), _dptr(w["root_w"]),
+                 ctypes.c_long(S), _dptr(B), None, None, ctypes.c_int(precise),
+                 ctypes.c_int(nthreads), _dptr(out))
+    return out
+
+
+def run_hess(root):
+    """src/arbplfhess.c:1163-1206 (_parse_second_order) + :1279-1343 (hess_query)"""
+    _strict_keys(root, ["model_and_data", "site_reduction"], [], "top level")
+    m = parse_model(root["model_and_data"])
+    if root["site_reduction"] is None:
+        _fail("site_reduction: null")
+    r_site = parse_reduction(root["site_reduction"], m.S, "site")
+    if r_site.mode == AGG_NONE:
+        _fail("aggregation over sites is required")
+    w = prepare(m)
+    sel = _selected_sites(r_site)
+    sw, div = _axis_weights(r_site)
+    H = np.zeros((m.E, m.E), dtype=np.longdouble)
+    if sel and m.E:
+        hs = site_hess(m, w, m.B[sel]).astype(np.longdouble)
+        for i, site in enumerate(sel):
+            H += hs[i] * sw[site] / div
+    rows = []
+    for first in range(m.E):
+        for second in range(m.E):
+            v = float(H[m.order[first], m.order[second]])
+            rows.append([first, second, 0.0 if v == 0.0 else v])
+    return {"columns": ["first_edge", "second_edge", "value"], "data": rows}
+
+
 def _string_api(fn, s):
     """src/arbplf.c:209-250: str -> str, RuntimeError on any failure."""
     try:
@@ -872,3 +914,7 @@ def arbplf_trans(s):
 
 def arbplf_em_update(s):
     return _string_api(run_em_update, s)
+
+
+def arbplf_hess(s):
+    return _string_api(run_hess, s)

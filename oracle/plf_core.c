@@ -559,3 +559,38 @@ int orc_edge_expect(int N, int E, int k, int C,
     }
     return used;
 }
+
+/* per-site Hessians of the log likelihood [S][E][E] (CSR edge order); src/arbplfhess.c:503-760.
+ * Returns the number of infeasible sites (their blocks are NaN). */
+int orc_hess(int N, int E, int k, int C,
+        const int *indptr, const int *indices, const int *preorder,
+        const void *P, const void *Qn, const double *cat_prior, const double *cat_rates,
+        int root_mode, const double *root_w,
+        long S, const double *B, const uint8_t *codes, const double *defs,
+        int precise /* 1 long double, 2 binary128 */, int nthreads, double *out)
+{
+    orc_problem pr;
+    fill_problem(&pr, N, E, k, C, indptr, indices, preorder, P, Qn, cat_prior, cat_rates,
+                 root_mode, root_w, B, codes, defs);
+    if (E < 1) return 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    int bad = 0;
+#pragma omp parallel reduction(+:bad)
+    {
+        void *ws = precise == 2 ? site_ws_alloc_q(&pr) : site_ws_alloc_ld(&pr);
+        void *H = malloc((size_t)E * E * sizeof(q128)), *g = malloc((size_t)E * sizeof(q128));
+#pragma omp for schedule(static)
+        for (long s = 0; s < S; s++) {
+            int rc = precise == 2 ? site_hess_q(&pr, ws, s, H, g, out + (size_t)s * E * E)
+                                  : site_hess_ld(&pr, ws, s, H, g, out + (size_t)s * E * E);
+            if (rc) {
+                bad++;
+                for (size_t i = 0; i < (size_t)E * E; i++) out[(size_t)s * E * E + i] = NAN;
+            }
+        }
+        free(H); free(g); free(ws);
+    }
+    return bad;
+}

@@ -176,3 +176,30 @@ def test_dwell_rewards_sum_to_one(oracle):
     """examples/BEAST.MarkovJumps/MarkovRewardsC: a reward of 1 for every state gives 1 on every branch"""
     got = _run(oracle.arbplf_dwell, os.path.join(EX, "BEAST.MarkovJumps/MarkovRewardsC/in.json"))
     assert all(abs(r[-1] - 1.0) <= 1e-15 for r in got["data"])
+
+
+HESS = _pairs(["Felsenstein.2004.fig.16.4/hess/with.full.data", "Felsenstein.2004.fig.16.4/hess/with.leaf.data",
+               "Felsenstein.2004.fig.16.4/hess/with.no.data"])
+
+
+@pytest.mark.parametrize("inp,outp", HESS, ids=[os.path.relpath(p[0], EX) for p in HESS])
+def test_hess_golden(oracle, inp, outp):
+    _compare(_run(oracle.arbplf_hess, inp), load_json(outp), rel=2e-15)
+
+
+def test_hess_is_derivative_of_deriv(oracle):
+    """the Hessian row of edge j is the central finite difference of the oracle's own gradient (8-digit check)"""
+    inp = os.path.join(EX, "Felsenstein.2004.fig.16.4/hess/with.leaf.data/in.json")
+    x = load_json(inp)
+    H = np.array([r[2] for r in _run(oracle.arbplf_hess, inp)["data"]]).reshape(7, 7)
+    rates = x["model_and_data"]["edge_rate_coefficients"]
+    for j in (0, 3, 6):
+        h = 1e-6 * rates[j]
+        g = []
+        for sgn in (+1, -1):
+            y = json.loads(json.dumps(x))
+            y["model_and_data"]["edge_rate_coefficients"][j] = rates[j] + sgn * h
+            y["edge_reduction"] = {}
+            g.append(np.array([r[-1] for r in json.loads(oracle.arbplf_deriv(json.dumps(y)))["data"]]))
+        fd = (g[0] - g[1]) / (2 * h)
+        assert np.max(np.abs(fd - H[j]) / np.maximum(np.abs(H[j]), 1.0)) < 1e-6
