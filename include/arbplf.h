@@ -38,10 +38,13 @@ char *arbplf_marginal_string(void *userdata, const char *s_in, int *retcode);
 char *arbplf_dwell_string(void *userdata, const char *s_in, int *retcode);
 char *arbplf_trans_string(void *userdata, const char *s_in, int *retcode);
 char *arbplf_em_update_string(void *userdata, const char *s_in, int *retcode);
+/* the Hessian of the log likelihood (hess_query behind arbplf_second_order_run,
+ * src/arbplfhess.c:1279-1343, :1736-1771), fp64 and uncertified */
+char *arbplf_hess_string(void *userdata, const char *s_in, int *retcode);
 
 /* Host-only validation of an input document (JSON grammar, model_and_data,
  * reductions) exactly as the corresponding query would perform it, without
- * touching the GPU.  what = "ll" | "deriv" | "marginal" | "dwell" | "trans" | "em_update".
+ * touching the GPU.  what = "ll" | "deriv" | "marginal" | "dwell" | "trans" | "em_update" | "hess".
  * 0 = accepted. */
 int arbplf_validate_string(const char *what, const char *s_in);
 

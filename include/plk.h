@@ -169,6 +169,14 @@ enum { PLK_FIT_EM = 0, PLK_FIT_LBFGS = 1 };
 int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, double ftol, const int *edge_mask,
                        double *rates_inout, double *ll_trace, int *iters_out, long *evals_out);
 
+/*
+ * Hessian of sum_s w_s ll_s with respect to the edge rate coefficients (SURVEY.md 8f-4, fp64 and
+ * uncertified): replaces _recompute_second_order of src/arbplfhess.c:503-760 with its helpers
+ * evaluate_site_derivatives (:343-437) and _lhood_hess_to_ll_hess (:455-493).
+ * hess_sums_out: [E][E][2] double-double entries, CSR edge order, symmetric.
+ */
+int plk_hess(plk_engine *h, double *hess_sums_out);
+
 /* Introspection for tests and profiling. */
 int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
 int plk_get_info(plk_engine *h, int what, long *out);

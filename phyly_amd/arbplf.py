@@ -76,6 +76,11 @@ def arbplf_em_update(s):
     return _call("arbplf_em_update", s)
 
 
+def arbplf_hess(s):
+    """Hessian of the log likelihood in the edge rate coefficients (src/arbplfhess.c:1279-1343), fp64"""
+    return _call("arbplf_hess", s)
+
+
 def _out_of_scope(name):
     def f(s):
         raise RuntimeError("arbplf likelihood error: %s is outside the MI355X hot path of this build" % name)
@@ -84,6 +89,6 @@ def _out_of_scope(name):
 
 
 # the reference module's other entry points (src/arbplf.c:521-534) are out of scope
-for _name in ("arbplf_hess", "arbplf_inv_hess",
+for _name in ("arbplf_inv_hess",
               "arbplf_newton_delta", "arbplf_newton_update", "arbplf_newton_refine"):
     globals()[_name] = _out_of_scope(_name)

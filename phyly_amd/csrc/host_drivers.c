@@ -240,7 +240,8 @@ static int query_parse(query *q, int kind, const jval *root)
     if (kind == 3 && host_reduction_parse(&q->r_b, q->m.k, "state", j_get(root, "state_reduction"))) return -1;
     if (kind == 4 && host_pair_reduction_parse(&q->r_b, &q->pair_first, &q->pair_second, q->m.k, "trans",
                                                j_get(root, "trans_reduction"))) return -1;
-    if (kind == 5 && q->r_site.agg_mode == AGG_NONE) { fprintf(stderr, "error: aggregation over sites is required\n"); return -1; }
+    if (kind == 6 && !j_get(root, "site_reduction")) { fprintf(stderr, "error: site_reduction is required\n"); return -1; }
+    if ((kind == 5 || kind == 6) && q->r_site.agg_mode == AGG_NONE) { fprintf(stderr, "error: aggregation over sites is required\n"); return -1; }
     return 0;
 }
 
@@ -624,6 +625,39 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------ hess */
+/* arbplf-hess (src/arbplfhess.c:1163-1206 _parse_second_order, :1279-1343 hess_query): the E x E matrix of
+ * second derivatives of the site-aggregated log likelihood, all user edges in order on both axes */
+static int run_hess(const jval *root, jbuf *out)
+{
+    query q;
+    int rc = -1;
+    double *hs = NULL;
+    query_init(&q);
+    if (query_parse(&q, 6, root)) goto done;
+    if (query_prepare(&q)) goto done;
+    const int E = q.m.E;
+    hs = calloc((size_t)E * E * 2 + 2, sizeof(double));
+    if (!hs) goto done;
+    if (q.U > 0 && E > 0 && plk_hess(q.eng, hs)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+    jbuf_puts(out, "{\"columns\": [\"first_edge\", \"second_edge\", \"value\"], \"data\": [");
+    for (int a = 0; a < E; a++)
+        for (int b = 0; b < E; b++) {
+            const size_t pos = (size_t)q.m.edge_order[a] * E + q.m.edge_order[b];
+            double v = clean(((long double)hs[2 * pos] + (long double)hs[2 * pos + 1]) / q.div_site);
+            if (check_finite(v, "a second derivative of the log likelihood")) goto done;
+            if (a || b) jbuf_puts(out, ", ");
+            jbuf_puts(out, "["); jbuf_int(out, a); jbuf_puts(out, ", "); jbuf_int(out, b); jbuf_puts(out, ", ");
+            jbuf_real(out, v); jbuf_puts(out, "]");
+        }
+    jbuf_puts(out, "]}");
+    rc = 0;
+done:
+    free(hs);
+    query_clear(&q);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ string API */
 static char *string_hom(int (*run)(const jval *, jbuf *), void *userdata, const char *s_in, int *retcode)
 {
@@ -657,14 +691,15 @@ char *arbplf_marginal_string(void *userdata, const char *s_in, int *retcode) { r
 char *arbplf_dwell_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_dwell, userdata, s_in, retcode); }
 char *arbplf_trans_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_trans, userdata, s_in, retcode); }
 char *arbplf_em_update_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_em_update, userdata, s_in, retcode); }
+char *arbplf_hess_string(void *userdata, const char *s_in, int *retcode) { return string_hom(run_hess, userdata, s_in, retcode); }
 
 /* Host-only validation (JSON grammar, model, reductions); no GPU is touched.
- * what: "ll", "deriv", "marginal", "dwell", "trans" or "em_update".  Returns 0 when the input would be accepted. */
+ * what: "ll", "deriv", "marginal", "dwell", "trans", "em_update" or "hess".  Returns 0 when the input would be accepted. */
 int arbplf_validate_string(const char *what, const char *s_in)
 {
     char err[256];
     int kind = !strcmp(what, "ll") ? 0 : !strcmp(what, "deriv") ? 1 : !strcmp(what, "marginal") ? 2 :
-               !strcmp(what, "dwell") ? 3 : !strcmp(what, "trans") ? 4 : !strcmp(what, "em_update") ? 5 : -1;
+               !strcmp(what, "dwell") ? 3 : !strcmp(what, "trans") ? 4 : !strcmp(what, "em_update") ? 5 : !strcmp(what, "hess") ? 6 : -1;
     if (kind < 0 || !s_in) return -1;
     json_doc *doc = json_doc_parse(s_in, err, sizeof err);
     if (!doc) { fprintf(stderr, "%s\n", err); return -1; }

@@ -578,6 +578,10 @@ struct UpArgs {
     const double *PT;    /* [C][E][K*K] transposed P:  PT[j*K+i] = P[i][j]  */
     const double *PN;    /* [C][E][K*K] plain P:       PN[i*K+j] = P[i][j]  */
     const double *DT;    /* [C][E][K*K] transposed dP: DT[j*K+i] = dP[i][j] */
+    /* second-order passes (plk_hess): edge mod_edge uses dP in the role of P and d2P = r^2 Q Q P in the
+     * role of dP; DN = plain dP, D2T = transposed d2P; LHdiv = likelihoods of the unmodified model */
+    int mod_edge;        /* -1: none */
+    const double *DN, *D2T, *LHdiv;
     const uint8_t *codes;
     const double *defs;  /* [nchar][K] */
     const double *B;     /* [N][k][S] */
@@ -676,7 +680,8 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
                     for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
                 }
                 double m[K];
-                up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, m);
+                if (idx == a.mod_edge) up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, m);
+                else up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, m);
                 /* leaf-edge vectors are not stored: the up pass recomputes them (k^2 flops vs 2k doubles of HBM) */
                 double *ev = a.EV + ((size_t)idx * a.C + c) * a.k * n + slc;
 #pragma unroll
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
     const long slc = valid ? sl : a.n - 1;
     const long sg = a.s0 + slc;
     const size_t n = (size_t)a.n;
-    const double inv = 1.0 / a.LH[slc];
+    const double inv = 1.0 / (a.LHdiv ? a.LHdiv[slc] : a.LH[slc]);
     const int root = as_uniform(a.preorder)[0];
 
     /* root: forward vector = root prior weights; its marginal */
@@ -784,7 +789,8 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                     if (as_uniform(a.indptr)[b2] == as_uniform(a.indptr)[b2 + 1]) {
                         double m2[K];
                         up_stage_obs<K>(a, b2, sg, tid, xs);
-                        up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx2) * K * K, a.k, xs, tid, m2);
+                        if (idx2 == a.mod_edge) up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx2) * K * K, a.k, xs, tid, m2);
+                        else up_matvec<K, 1>(a.PT + ((size_t)c * a.E + idx2) * K * K, a.k, xs, tid, m2);
 #pragma unroll
                         for (int i = 0; i < K; i++) fe[i] *= m2[i];
                     } else {
@@ -803,7 +809,8 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                         for (int j = 0; j < a.k; j++) xs[j][tid] = lb[(size_t)j * n];
                     }
                     double y[K];
-                    if (a.dzero) up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
+                    if (idx == a.mod_edge) up_matvec<K, 2>(a.D2T + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
+                    else if (a.dzero) up_matvec<K, 2>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
                     else up_matvec<K, 0>(a.DT + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, y);
                     double d = 0.0;
 #pragma unroll
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
 #pragma unroll
                     for (int i = 0; i < K; i++) xs[i][tid] = fe[i];
                     double fb[K];
-                    up_matvec<K, 0>(a.PN + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, fb);
+                    up_matvec<K, 0>((idx == a.mod_edge ? a.DN : a.PN) + ((size_t)c * a.E + idx) * K * K, a.k, xs, tid, fb);
                     if (!b_leaf) {
                         double *fo = a.FN + ((size_t)b * a.C + c) * a.k * n + slc;
 #pragma unroll
@@ -1861,6 +1868,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
         a.dzero = dzero;
+        a.mod_edge = -1; a.DN = nullptr; a.D2T = nullptr; a.LHdiv = nullptr;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
@@ -2153,5 +2161,187 @@ extern "C" int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, doubl
     std::copy(rates.begin(), rates.end(), rates_inout);
     if (iters_out) *iters_out = it;
     if (evals_out) *evals_out = evals;
+    return PLK_OK;
+}
+
+/* ====================================================================== */
+/* Second derivatives of the log likelihood               */
+/* ====================================================================== */
+
+/* d2P[c][e] = r_c^2 * (Qn Qn) * P[c][e], accumulated in double-double from the unrounded P */
+__global__ void k_d2p(int k, int E, const double *__restrict__ Q2 /* [2][k*k] hi, lo */, const dd *__restrict__ Pdd,
+                      const double *__restrict__ cat_rates, double *__restrict__ out)
+{
+    const int ce = blockIdx.x, c = ce / E;
+    const int kk = k * k;
+    const dd *P = Pdd + (size_t)ce * kk;
+    const double r = cat_rates[c];
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+        const int i = idx / k, j = idx - i * k;
+        dd acc = dd_make(0.0, 0.0);
+        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(dd_make(Q2[i * k + l], Q2[kk + i * k + l]), P[l * k + j]));
+        acc = dd_mul_d(dd_mul_d(acc, r), r);
+        out[(size_t)ce * kk + idx] = acc.hi;
+    }
+}
+
+/* G[i][j] = sum_s w_s D[i][s] D[j][s] for i >= j, one workgroup per pair, double-double accumulation */
+__global__ __launch_bounds__(256) void k_gram(int E, long n, const double *__restrict__ D, const double *__restrict__ w,
+                                              dd *__restrict__ out)
+{
+    const int i = blockIdx.x, j = blockIdx.y;
+    if (j > i) return;
+    const double *di = D + (size_t)i * n, *dj = D + (size_t)j * n;
+    dd acc = dd_make(0.0, 0.0);
+    for (long s = threadIdx.x; s < n; s += 256) {
+        dd p = dd_two_prod(di[s], dj[s]);
+        if (w) p = dd_mul_d(p, w[s]);
+        acc = dd_add(acc, p);
+    }
+    acc = dd_block_sum(acc);
+    if (threadIdx.x == 0) out[(size_t)i * E + j] = acc;
+}
+
+template <int K>
+static void launch_hess_pass(plk_engine *h, const UpArgs &a, unsigned grid)
+{
+    hipLaunchKernelGGL(k_down_store<K>, dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+    hipLaunchKernelGGL((k_up<K, true, false>), dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
+}
+
+static void launch_hess_pass_k(plk_engine *h, const UpArgs &a, unsigned grid)
+{
+    switch (h->K) {
+    case 2: launch_hess_pass<2>(h, a, grid); break;
+    case 4: launch_hess_pass<4>(h, a, grid); break;
+    case 8: launch_hess_pass<8>(h, a, grid); break;
+    case 16: launch_hess_pass<16>(h, a, grid); break;
+    case 20: launch_hess_pass<20>(h, a, grid); break;
+    case 32: launch_hess_pass<32>(h, a, grid); break;
+    case 61: launch_hess_pass<61>(h, a, grid); break;
+    default: launch_hess_pass<64>(h, a, grid); break;
+    }
+}
+
+/*
+ * Hessian of sum_s w_s ll_s with respect to the edge rate coefficients (CSR edge order), replacing
+ * _recompute_second_order of src/arbplfhess.c:503-760 for the fp64, uncertified case.
+ *
+ *   d^2 ll / dr_i dr_j = H_ij / f - (g_i / f)(g_j / f)            (src/arbplfhess.c:455-493)
+ * with f the site likelihood, g its gradient and H its Hessian.  g_i / f is the ordinary derivative pass.
+ * Row j of H is obtained from the same two kernels run on a modified model in which edge j carries
+ * dP_j = r Q P_j in the role of P_j and r^2 Q Q P_j in the role of dP_j: the derivative of that model with
+ * respect to edge i is the second derivative (i, j) of the original one -- the reference's substitution of Q
+ * along both root paths (src/arbplfhess.c:343-437) done for all i at once in O(E k^2) per site and row.
+ * E + 1 passes per site chunk; vector kernels (no rescaling: site likelihoods must stay above ~1e-300).
+ */
+extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
+{
+    if (!h || !hess_sums_out) return PLK_E_ARG;
+    if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_hess: tree, model and patterns must be set"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
+    const long S = h->S;
+    const size_t kk = (size_t)k * k, strm = (size_t)C * E * K * K;
+    if (E == 0) return PLK_OK;
+
+    /* Qn^2 in double-double on the host */
+    std::vector<double> Q2(2 * kk);
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            dd acc = dd_make(0.0, 0.0);
+            for (int l = 0; l < k; l++)
+                acc = dd_add(acc, dd_mul(dd_make(h->Qn[(size_t)i * k + l], h->Qn[kk + (size_t)i * k + l]),
+                                         dd_make(h->Qn[(size_t)l * k + j], h->Qn[kk + (size_t)l * k + j])));
+            Q2[(size_t)i * k + j] = acc.hi; Q2[kk + (size_t)i * k + j] = acc.lo;
+        }
+    double *d_Q2 = nullptr, *d_d2P = nullptr, *d_PT = nullptr, *d_PN = nullptr, *d_DT = nullptr, *d_DN = nullptr, *d_D2T = nullptr;
+    double *d_LH0 = nullptr, *d_D0 = nullptr;
+    dd *d_G = nullptr;
+    int *d_has = nullptr;
+    auto cleanup = [&]() {
+        void *ps[] = {d_Q2, d_d2P, d_PT, d_PN, d_DT, d_DN, d_D2T, d_LH0, d_D0, d_G, d_has};
+        for (void *p : ps) if (p) (void)hipFree(p);
+    };
+    if ((rc = dev_upload(h, &d_Q2, Q2.data(), Q2.size())) || (rc = dev_alloc(h, &d_d2P, (size_t)C * E * kk)) ||
+        (rc = dev_alloc(h, &d_PT, strm)) || (rc = dev_alloc(h, &d_PN, strm)) || (rc = dev_alloc(h, &d_DT, strm)) ||
+        (rc = dev_alloc(h, &d_DN, strm)) || (rc = dev_alloc(h, &d_D2T, strm)) || (rc = dev_alloc(h, &d_G, (size_t)E * E))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(k_d2p, dim3(C * E), dim3(kk >= 256 ? 256 : 64), 0, h->stream, k, E, d_Q2, h->d_Pdd, h->d_cat_rates, d_d2P);
+    const int bt = K * K >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_P, d_PT);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 1, h->d_P, d_PN);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_dP, d_DT);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 1, h->d_dP, d_DN);
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, d_d2P, d_D2T);
+    if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_hess: matrix set-up failed"; return PLK_E_DEVICE; }
+    if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
+
+    const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + 2 + 2 * (size_t)E) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
+    budget += h->work_cap * sizeof(double);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
+    if (chunk < 1) { cleanup(); h->err = "plk_hess: not enough device memory for one site"; return PLK_E_NOMEM; }
+    if (chunk < S) chunk = std::max<long>(GEN_BLOCK, chunk / GEN_BLOCK * GEN_BLOCK);
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, ((size_t)(E + 2 * (size_t)N) * C * k + 1 + (size_t)E) * (size_t)chunk)) ||
+        (rc = dev_alloc(h, &d_LH0, (size_t)chunk)) || (rc = dev_alloc(h, &d_D0, (size_t)E * chunk))) { cleanup(); return rc; }
+
+    std::vector<long double> Hrow((size_t)E * E, 0.0L), G((size_t)E * E, 0.0L);
+    std::vector<dd> gh((size_t)E * E);
+    for (long s0 = 0; s0 < S; s0 += chunk) {
+        const long n = std::min(chunk, S - s0);
+        UpArgs a;
+        a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
+        a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
+        a.dzero = 1;
+        a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
+        a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.DN = d_DN; a.D2T = d_D2T;
+        a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
+        a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = nullptr; a.node_mask = nullptr;
+        double *p = h->d_work;
+        a.EV = p; p += (size_t)E * C * k * n;
+        a.LN = p; p += (size_t)N * C * k * n;
+        a.FN = p; p += (size_t)N * C * k * n;
+        a.LH = p; p += n;
+        a.DV = p; p += (size_t)E * n;
+        a.MV = nullptr;
+        const unsigned grid = (unsigned)((n + GEN_BLOCK - 1) / GEN_BLOCK);
+        const double *w = h->d_w ? h->d_w + s0 : nullptr;
+        /* pass 0: the model itself -> f and g / f */
+        a.mod_edge = -1; a.LHdiv = nullptr;
+        launch_hess_pass_k(h, a, grid);
+        hipError_t e = hipMemcpyAsync(d_LH0, a.LH, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_D0, a.DV, (size_t)E * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gram, dim3(E, E), dim3(256), 0, h->stream, E, n, d_D0, w, d_G);
+            e = hipMemcpyAsync(gh.data(), d_G, (size_t)E * E * sizeof(dd), hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { cleanup(); h->err = std::string("plk_hess: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+        for (int i = 0; i < E; i++)
+            for (int j = 0; j <= i; j++) G[(size_t)i * E + j] += (long double)gh[(size_t)i * E + j].hi + (long double)gh[(size_t)i * E + j].lo;
+        /* passes 1..E: row j of the likelihood Hessian, normalised by the unmodified likelihood */
+        a.LHdiv = d_LH0;
+        for (int j = 0; j < E; j++) {
+            a.mod_edge = j;
+            launch_hess_pass_k(h, a, grid);
+            if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_hess: kernel launch failed"; return PLK_E_DEVICE; }
+            if ((rc = wsum_rows(h, E, n, a.DV, w, Hrow.data() + (size_t)j * E))) { cleanup(); return rc; }
+        }
+    }
+    cleanup();
+    for (int i = 0; i < E; i++)
+        for (int j = 0; j <= i; j++) {
+            /* both triangles of the likelihood Hessian were computed; average them */
+            const long double v = (Hrow[(size_t)i * E + j] + Hrow[(size_t)j * E + i]) * 0.5L - G[(size_t)i * E + j];
+            const double hi = (double)v, lo = (double)(v - (long double)hi);
+            hess_sums_out[2 * ((size_t)i * E + j)] = hess_sums_out[2 * ((size_t)j * E + i)] = hi;
+            hess_sums_out[2 * ((size_t)i * E + j) + 1] = hess_sums_out[2 * ((size_t)j * E + i) + 1] = lo;
+        }
     return PLK_OK;
 }

@@ -58,6 +58,7 @@ def load_library():
     lib.plk_edge_expect.argtypes = [vp, vp, vp, ci, vp, vp, vp]
     lib.plk_get_frechet_matrices.argtypes = [vp, vp, vp, ci, vp]
     lib.plk_fit_edge_rates.argtypes = [vp, ci, ci, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ci), ctypes.POINTER(cl)]
+    lib.plk_hess.argtypes = [vp, vp]
     lib.plk_get_transition_matrices.argtypes = [vp, vp]
     lib.plk_get_info.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.plk_set_option.argtypes = [vp, ci, cl]
@@ -210,6 +211,12 @@ class Engine:
         self._check(self._lib.plk_fit_edge_rates(self._h, int(method), int(max_iter), float(ftol), _ptr(mask), _ptr(r),
                                                  _ptr(trace), ctypes.byref(iters), ctypes.byref(evals)))
         return r, trace[:iters.value + 1].copy(), evals.value
+
+    def hess(self):
+        """[E][E] Hessian of the weighted log likelihood in the edge rates (CSR order), as hi + lo"""
+        out = np.zeros((self.E, self.E, 2))
+        self._check(self._lib.plk_hess(self._h, _ptr(out)))
+        return out[..., 0] + out[..., 1]
 
     def transition_matrices(self):
         P = np.empty((self.C, self.E, self.k, self.k))

@@ -1,0 +1,125 @@
+"""GPU parity of arbplf-hess / plk_hess (SURVEY.md 8f-4, fp64 and uncertified) against the reference's three
+golden files, the binary128 oracle, and the engine's own gradient by finite differences.
+
+Tolerance: |d| <= 1e-11 * max(|expected|, largest entry of the matrix) -- the Hessian of a log likelihood is a
+difference H/f - g g^T/f^2 of quantities that are individually larger than the result."""
+import copy
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_json, oracle_model
+
+pytestmark = pytest.mark.gpu
+EX = os.path.join(GOLDEN, "examples")
+HESS_DIRS = ["with.full.data", "with.leaf.data", "with.no.data"]
+
+
+def _check(got, want, rel=1e-11):
+    assert got["columns"] == want["columns"] == ["first_edge", "second_edge", "value"]
+    assert len(got["data"]) == len(want["data"])
+    scale = max(abs(r[-1]) for r in want["data"])
+    for a, b in zip(got["data"], want["data"]):
+        assert a[:2] == b[:2]
+        assert abs(a[2] - b[2]) <= rel * max(abs(b[2]), scale) + 1e-25, (a, b)
+
+
+@pytest.mark.parametrize("d", HESS_DIRS)
+def test_reference_goldens(d):
+    import arbplf
+    base = os.path.join(EX, "Felsenstein.2004.fig.16.4/hess", d)
+    with open(os.path.join(base, "in.json")) as f:
+        got = json.loads(arbplf.arbplf_hess(f.read()))
+    _check(got, load_json(os.path.join(base, "out.json")))
+
+
+def test_cli_and_required_aggregation():
+    import arbplf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = os.path.join(EX, "Felsenstein.2004.fig.16.4/hess/with.leaf.data")
+    with open(os.path.join(base, "in.json")) as f:
+        r = subprocess.run([os.path.join(root, "phyly_amd", "csrc", "arbplf-hess")], stdin=f, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    _check(json.loads(r.stdout), load_json(os.path.join(base, "out.json")))
+    x = load_json(os.path.join(base, "in.json"))
+    for bad in ({k: v for k, v in x.items() if k != "site_reduction"},       # site_reduction is required
+                dict(x, site_reduction={"selection": [0]}),                    # ... and must aggregate
+                dict(x, edge_reduction={"aggregation": "sum"})):              # edge reduction is forbidden
+        with pytest.raises(RuntimeError):
+            arbplf.arbplf_hess(json.dumps(bad))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from phyly_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("T,k,model,S", [(10, 4, "gtr_g4", 60), (12, 4, "hky85", 40), (5, 20, "aa20", 12)])
+def test_engine_matches_oracle(eng, oracle, T, k, model, S):
+    from phyly_amd import synth
+    w = synth.Workload(T=T, k=k, tree="yule", model=model, seed=21)
+    w.setup_engine(eng)
+    codes = w.simulate(S)
+    m, ow = oracle_model(oracle, w, codes)
+    eng.set_patterns_codes(codes, w.defs)
+    wts = np.linspace(0.5, 1.5, S)
+    eng.set_site_weights(wts)
+    want = (oracle.site_hess(m, ow, w.defs[codes.T], precise=2 if k <= 4 else 1).astype(np.longdouble)
+            * wts[:, None, None].astype(np.longdouble)).sum(axis=0).astype(float)
+    got = eng.hess()
+    eng.set_site_weights(None)
+    assert np.allclose(got, got.T, rtol=0, atol=0)
+    assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want))
+
+
+def test_hessian_is_jacobian_of_gradient(eng):
+    """size-independent property at a larger size: H e_j ~ (grad(r + h e_j) - grad(r - h e_j)) / 2h"""
+    from phyly_amd import synth
+    w = synth.Workload(T=24, k=4, tree="yule", model="gtr_g4", seed=9)
+    w.setup_engine(eng)
+    codes = w.simulate(20000)
+    eng.set_patterns_codes(codes, w.defs)
+    eng.set_site_weights(None)
+    H = eng.hess()
+    r0 = w.edge_rates_csr.copy()
+    for j in (0, 7, w.E - 1):
+        h = 1e-5 * r0[j]
+        g = []
+        for sgn in (1, -1):
+            r = r0.copy()
+            r[j] += sgn * h
+            eng.update_edge_rates(r)
+            _, s = eng.deriv(per_site=False)
+            g.append(s[:, 0] + s[:, 1])
+        fd = (g[0] - g[1]) / (2 * h)
+        assert np.max(np.abs(fd - H[j])) <= 1e-6 * np.max(np.abs(H[j]))
+    eng.update_edge_rates(r0)
+
+
+def test_random_inputs_match_oracle(oracle):
+    import arbplf
+    from test_gpu_differential import random_model
+    rng = random.Random(77)
+    done = 0
+    for _ in range(40):
+        x = random_model(rng, "ll")
+        sr = x.get("site_reduction") or {}
+        if "aggregation" not in sr:
+            sr["aggregation"] = rng.choice(["sum", "avg"])
+        x["site_reduction"] = sr
+        s = json.dumps(x)
+        want = json.loads(oracle.arbplf_hess(s))
+        if any(not np.isfinite(r[-1]) for r in want["data"]):
+            with pytest.raises(RuntimeError):
+                arbplf.arbplf_hess(s)
+            continue
+        _check(json.loads(arbplf.arbplf_hess(s)), want, rel=1e-10)
+        done += 1
+    assert done >= 20

@@ -37,7 +37,8 @@ def validate():
 
 def _oracle_accepts(oracle, obj, kind="ll"):
     fn = {"ll": oracle.run_ll, "deriv": oracle.run_deriv, "marginal": oracle.run_marginal,
-          "dwell": oracle.run_dwell, "trans": oracle.run_trans, "em_update": oracle.run_em_update}[kind]
+          "dwell": oracle.run_dwell, "trans": oracle.run_trans, "em_update": oracle.run_em_update,
+          "hess": oracle.run_hess}[kind]
     try:
         fn(copy.deepcopy(obj))
         return True
@@ -260,8 +261,12 @@ def test_dwell_trans_em_reductions(validate, oracle):
     both(x, "dwell", True)
     both(x, "trans", True)
     both(x, "em_update", False)                         # needs a site aggregation
+    both(x, "hess", False)                              # site_reduction itself is required (src/arbplfhess.c:1178-1182)
+    x["site_reduction"] = {"selection": [0]}
+    both(x, "hess", False)                              # ... and must aggregate
     x["site_reduction"] = {"aggregation": "sum"}
     both(x, "em_update", True)
+    both(x, "hess", True)
     x["edge_reduction"] = {"aggregation": "sum"}
     both(x, "em_update", False)                         # edge_reduction is unknown to em-update
     both(x, "dwell", True)
