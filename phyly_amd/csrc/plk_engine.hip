@@ -107,6 +107,8 @@ struct plk_engine {
     double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
     double *d_frag = nullptr; size_t frag_cap = 0;   /* MFMA A fragments */
     double *d_root_wd = nullptr;         /* root weights, distributed layout */
+    int4 *d_mops = nullptr;              /* MFMA program (observation ops chained for the value prefetch) */
+    int mfma_first_slot = -1, mfma_first_row = 0;
     bool mfma_dirty = true;
     size_t ps_cap = 0, tip_cap = 0;
 
@@ -924,7 +926,7 @@ extern "C" void plk_destroy(plk_engine *h)
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
                     h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
-                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1476,6 +1478,28 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
             if ((rc = dev_upload(h, &h->d_root_wd, rwd.data(), rwd.size()))) return rc;
             if ((rc = dev_reserve(h, &h->d_frag, &h->frag_cap, (size_t)h->C * nops * T * kk4 * 64))) return rc;
             if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4 * R))) return rc;
+            {   /* MFMA program: observation ops name their staged code row and the next observation op */
+                std::vector<int> row(h->N, -1);
+                for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
+                std::vector<int4> mops(nops);
+                int first = -1, prev = -1;
+                for (int pc = 0; pc < nops; pc++) {
+                    const int code = h->ops[pc].x & 0xff;
+                    int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
+                    if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                        const int slot = code == OP_NODE_MUL ? ntips : (o.x >> 8);
+                        o.y = row[h->ops[pc].y];
+                        if (first < 0) { first = pc; h->mfma_first_slot = slot; h->mfma_first_row = o.y; }
+                        if (prev >= 0) { mops[prev].z = slot; mops[prev].w = o.y; }
+                        prev = pc;
+                    }
+                    mops[pc] = o;
+                }
+                if (prev >= 0) { mops[prev].z = h->mfma_first_slot | (1 << 30); mops[prev].w = h->mfma_first_row; }
+                else h->mfma_first_slot = -1;
+                if ((rc = dev_upload(h, &h->d_mops, mops.data(), mops.size()))) return rc;
+                if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
+            }
             hipLaunchKernelGGL(k_build_frag, dim3(nops, h->C), dim3(256), 0, h->stream,
                                h->k, T, kk4, h->E, nops, h->d_op_edge, h->d_P, h->d_frag);
             hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, h->C), dim3(256), 0, h->stream,
@@ -1486,11 +1510,13 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         MfmaArgs a;
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.kk4 = kk4; a.C = h->C; a.nops = nops; a.ntips = ntips;
-        a.nchar = h->nchar; a.root_mode = h->root_mode; a.ops = h->d_ops; a.frag = h->d_frag; a.tip = h->d_tip;
+        a.nchar = h->nchar; a.root_mode = h->root_mode; a.ops = h->d_mops; a.frag = h->d_frag; a.tip = h->d_tip;
+        a.obs_nodes = h->d_obs_nodes; a.nobs = (int)h->obs_nodes.size();
+        a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
         a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
         a.partial = sum_out ? h->d_partial + 4 : nullptr;
-        const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
+        const size_t lds = (size_t)T * kk4 * 64 * sizeof(double) + (size_t)a.nobs * MF_SITES;
         if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 3) hipLaunchKernelGGL(k_ll_mfma<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);

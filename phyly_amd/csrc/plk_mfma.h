@@ -31,7 +31,9 @@ typedef double plk_d4 __attribute__((ext_vector_type(4)));
 struct MfmaArgs {
     long S, Spad;
     int k, kk4, C, nops, ntips, nchar, root_mode;
-    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot */
+    const int4 *ops;          /* x = opcode | tip<<8, y = staged code row (observation ops) / slot */
+    const int *obs_nodes;     /* nobs nodes whose code rows are staged in LDS */
+    int nobs, first_slot, first_row;   /* first observation op of the program (first_slot < 0: none) */
     const double *frag;       /* [C][nops][T][kk4][64] A fragments of P (zero padded) */
     const double *tip;        /* [C][ntips+1][nchar][4][4T]: [lane group][register], last slot = raw definitions */
     const uint8_t *codes;     /* [N][Spad] */
@@ -47,16 +49,28 @@ struct MfmaArgs {
 template <int T>
 __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
 {
-    extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles */
+    extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles, then nobs x 64 staged pattern codes */
     constexpr int R = 4 * T;                      /* registers (states) per lane */
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4;                      /* lane group = state residue mod 4 */
     const long site = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
     const bool valid = site < a.S;
-    const long sc = valid ? site : a.S - 1;
     const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;   /* lane-linear index for slots */
     const int nfrag = T * a.kk4 * 64;
+
+    /* stage the code rows of this block's 64 sites (rows are padded to Spad, a multiple of 1024) */
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_frag + nfrag);
+    {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
+        for (int idx = tid; idx < a.nobs * (MF_SITES / 4); idx += MF_BLOCK) {
+            const int row = idx / (MF_SITES / 4), col = idx - row * (MF_SITES / 4);
+            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad +
+                                                          (size_t)blockIdx.x * MF_SITES)[col];
+        }
+    }
+    __syncthreads();
+    const int scol = wave * 16 + (lane & 15);
 
     double sum = 0.0;
     int Eexp = 0;
@@ -68,9 +82,11 @@ __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
         for (int r = 0; r < R; r++) x[r] = 1.0;
         int esc = 0;
         for (int pc = 0; pc < a.nops; pc++) {
-            int2 op;
-            op.x = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc];
-            op.y = as_uniform(reinterpret_cast<const int *>(a.ops))[2 * pc + 1];
+            int4 op;
+            op.x = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc];
+            op.y = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 1];
+            op.z = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 2];
+            op.w = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 3];
             const int code = op.x & 0xff;
             if (code == OP_MATVEC) {
                 /* stage the A fragments of this edge (same for all 4 waves) */
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
                 }
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
                 const int t = code == OP_NODE_MUL ? a.ntips : (op.x >> 8);
-                const int ch = a.codes[(size_t)op.y * a.Spad + sc];
+                const int ch = code_lds[op.y * MF_SITES + scol];
                 const double2 *tp = reinterpret_cast<const double2 *>(
                     a.tip + ((((size_t)c * (a.ntips + 1) + t) * a.nchar + ch) * 4 + g) * R);
                 if (code == OP_TIP_SET) {
