@@ -429,6 +429,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
+#include "plk_fused4_asm2.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_updown4.h"
@@ -1451,6 +1452,15 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
             const size_t lds_asm = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * (aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
             if (h->slots_needed <= 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
             else hipLaunchKernelGGL(k_ll_fused4_asm<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+        } else if (NS == 2 && h->asm_ok && h->opt_fused_asm) {
+            /* two sites per lane in the assembly interpreter: 512-site tiles */
+            FusedAsmArgs aa;
+            aa.f = a; aa.words = h->d_words;
+            aa.first_tip = h->asm_first_tip; aa.first_row = h->asm_first_row; aa.second_row = h->asm_second_row;
+            aa.pack4 = h->nchar <= 16 ? 1 : 0;
+            const size_t lds_asm = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * (aa.pack4 ? PLK_TILE : 2 * PLK_TILE);
+            if (h->slots_needed <= 4) hipLaunchKernelGGL(k_ll_fused4_asm2<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            else hipLaunchKernelGGL(k_ll_fused4_asm2<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
         } else if (NS == 2) {
             if (h->slots_needed <= 4) launch_fused<4, 2>(h, a, grid, lds);
             else launch_fused<8, 2>(h, a, grid, lds);

@@ -105,3 +105,45 @@ def test_deep_scaling_no_underflow(eng, oracle):
     got, _ = eng.ll()
     assert np.all(np.isfinite(got))
     assert rel_err(got, want) <= TOL
+
+
+@pytest.mark.parametrize("ns", [1, 2])
+def test_fused_assembly_variants(eng, oracle, ns):
+    """both assembly interpreters (one and two sites per lane; 256- and 512-site tiles), ragged sizes, a
+    caterpillar-like tree that needs the 8-slot stack, more than 16 character definitions (unpacked codes)"""
+    from phyly_amd import synth, engine as E
+    eng.set_option(E.OPT_FUSED_NS, ns)
+    try:
+        for cfg, sizes in ((3, (1, 255, 513, 1500)), (2, (700,))):
+            w = _workload(cfg)
+            w.setup_engine(eng)
+            for S in sizes:
+                codes = w.random_codes(S, seed=S)
+                want = oracle_site_ll(oracle, w, codes)
+                eng.set_patterns_codes(codes, w.defs)
+                eng.set_site_weights(None)
+                got, (hi, lo) = eng.ll()
+                assert eng.info(E.INFO_LL_KERNEL) == 1
+                assert rel_err(got, want) <= TOL, (cfg, S)
+                assert abs((hi + lo) - float(np.sum(want.astype(np.longdouble)))) <= TOL * abs(np.sum(want))
+        w = synth.Workload(T=300, k=4, tree="yule", model="gtr_g4", seed=5)
+        w.setup_engine(eng)
+        codes = w.simulate(777)
+        eng.set_patterns_codes(codes, w.defs)
+        got, _ = eng.ll()
+        assert rel_err(got, oracle_site_ll(oracle, w, codes)) <= TOL
+        # 20 character definitions: codes are staged one per byte
+        w = _workload(2)
+        w.setup_engine(eng)
+        rng = np.random.default_rng(8)
+        defs = np.vstack([np.eye(4), np.ones((1, 4)), rng.integers(0, 2, (15, 4)).astype(float)])
+        defs[defs.sum(axis=1) == 0] = 1.0
+        codes = rng.integers(0, 20, (w.N, 900)).astype(np.uint8)
+        m, ow = oracle_model(oracle, w, codes[:, :1] % 5)
+        want, _ = oracle.site_ll(m, ow, codes=np.ascontiguousarray(codes.T), defs=defs)
+        eng.set_patterns_codes(codes, defs)
+        got, _ = eng.ll()
+        assert eng.info(E.INFO_LL_KERNEL) == 1
+        assert rel_err(got, want) <= TOL
+    finally:
+        eng.set_option(E.OPT_FUSED_NS, 0)
