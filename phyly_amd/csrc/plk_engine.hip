@@ -585,6 +585,10 @@ struct UpArgs {
      * role of dP; DN = plain dP, D2T = transposed d2P; LHdiv = likelihoods of the unmodified model */
     int mod_edge;        /* -1: none */
     const double *DN, *D2T, *LHdiv;
+    /* exact power-of-two rescaling (deriv / marginal / edge expectations; off for the Hessian passes):
+     * node_scale[N] = slot or -1 (null = no rescaling), SC[(slot*C + c)][n] = 2^-e, CW[C][n] = 2^(X_c - Xmax) */
+    const int *node_scale;
+    double *SC, *CW, *XC;
     const uint8_t *codes;
     const double *defs;  /* [nchar][K] */
     const double *B;     /* [N][k][S] */
@@ -662,8 +666,10 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
     const long sg = a.s0 + slc;
     const size_t n = (size_t)a.n;
     double lh_total = 0.0;
+    int xmax = INT_MIN;
     for (int c = 0; c < a.C; c++) {
         double lh_c = 0.0;
+        int X = 0;
         for (int u = a.N - 1; u >= 0; u--) {
             const int nd = as_uniform(a.preorder)[u];
             const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
@@ -693,6 +699,21 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
                     acc[i] *= m[i];
                 }
             }
+            const int slot = a.node_scale ? as_uniform(a.node_scale)[nd] : -1;
+            if (slot >= 0) {
+                double mx = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) mx = fmax(mx, acc[i]);
+                double sc = 1.0;
+                if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                    const int e = ilogb(mx);
+                    sc = ldexp(1.0, -e);
+#pragma unroll
+                    for (int i = 0; i < K; i++) acc[i] *= sc;
+                    X += e;
+                }
+                if (valid) a.SC[((size_t)slot * a.C + c) * n + sl] = sc;
+            }
             double *ln = a.LN + ((size_t)nd * a.C + c) * a.k * n + slc;
 #pragma unroll
             for (int i = 0; i < K; i++)
@@ -709,7 +730,19 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
                 }
             }
         }
-        lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total);
+        if (!a.node_scale) { lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total); continue; }
+        lh_c *= as_uniform(a.cat_prior)[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid) { a.XC[(size_t)c * n + sl] = (double)X; a.CW[(size_t)c * n + sl] = lh_c; }
+    }
+    if (a.node_scale && valid) {
+        /* combine the categories at the largest exponent: LH = sum_c prior_c lh_c 2^(X_c - Xmax) */
+        if (xmax == INT_MIN) xmax = 0;
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + sl] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + sl], w, lh_total);
+            a.CW[(size_t)c * n + sl] = w;
+        }
     }
     if (valid) a.LH[sl] = lh_total;
 }
@@ -747,7 +780,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
             for (int i = 0; i < K; i++) {
                 if (i < a.k) {
                     if (valid) fr[(size_t)i * n] = as_uniform(a.root_w)[i];
-                    if (MARG) macc[i] = fma(as_uniform(a.cat_prior)[c] * as_uniform(a.root_w)[i], lr[(size_t)i * n], macc[i]);
+                    if (MARG) macc[i] = fma(as_uniform(a.cat_prior)[c] * (a.CW ? a.CW[(size_t)c * n + slc] : 1.0) * as_uniform(a.root_w)[i], lr[(size_t)i * n], macc[i]);
                 }
             }
         }
@@ -766,6 +799,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
         double bnd[K];
         const bool has = as_uniform(a.node_has_data)[nd];
         if (has) up_load_obs_reg<K>(a, nd, sg, bnd);
+        const int slot = a.node_scale ? as_uniform(a.node_scale)[nd] : -1;
         for (int idx = start; idx < stop; idx++) {
             const int b = as_uniform(a.indices)[idx];
             const bool b_leaf = as_uniform(a.indptr)[b] == as_uniform(a.indptr)[b + 1];
@@ -786,6 +820,11 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
 #pragma unroll
                     for (int i = 0; i < K; i++) fe[i] *= bnd[i];
                 }
+                if (slot >= 0) {
+                    const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] *= sc;
+                }
                 for (int idx2 = start; idx2 < stop; idx2++) {
                     if (idx2 == idx) continue;
                     const int b2 = as_uniform(a.indices)[idx2];
@@ -803,7 +842,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
                             if (i < a.k) fe[i] *= ev[(size_t)i * n];
                     }
                 }
-                const double prior = as_uniform(a.cat_prior)[c];
+                const double prior = as_uniform(a.cat_prior)[c] * (a.CW ? a.CW[(size_t)c * n + slc] : 1.0);
                 if (want_d) {
                     /* y = dP_e * L_b ; d = fe . y */
                     if (b_leaf) up_stage_obs<K>(a, b, sg, tid, xs);
@@ -1633,18 +1672,21 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     te.push_back(-1);
     std::vector<double> rwd((size_t)4 * R, 0.0);
     for (int i = 0; i < k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
+    std::vector<int> node_scale(N, -1);
+    int nsc = 0;
+    for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr;
     double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)E)) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)E)) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
-        (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) ||
+        (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) || (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
         (rc = dev_alloc(h, &d_fP, nfr)) || (rc = dev_alloc(h, &d_fPT, nfr)) || (rc = dev_alloc(h, &d_fD, nfr)) ||
         (rc = dev_alloc(h, &d_tipd, ntab)) || (rc = dev_alloc(h, &d_dtip, ntab))) { cleanup(); return rc; }
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
@@ -1660,7 +1702,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
                        k, R, E, ntips, h->nchar, d_te, d_M, h->d_defs, h->K, d_dtip, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -1689,6 +1731,10 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         a.EV = p; p += (size_t)nie * C * R * a.stride;
         a.LN = p; p += (size_t)nin * C * R * a.stride;
         a.FN = p; p += (size_t)nin * C * R * a.stride;
+        a.node_scale = d_ns;
+        a.SC = p; p += (size_t)nsc * C * n;
+        a.CW = p; p += (size_t)C * n;
+        a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * k * n;
@@ -1864,7 +1910,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     /* padded edge-indexed streams */
     double *d_PT = nullptr, *d_PN = nullptr, *d_DT = nullptr;
     int *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr;
     const size_t strm = (size_t)C * E * K * K;
     auto cleanup = [&]() {
         if (d_PT) (void)hipFree(d_PT);
@@ -1873,6 +1919,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         if (d_emask) (void)hipFree(d_emask);
         if (d_nmask) (void)hipFree(d_nmask);
         if (d_has) (void)hipFree(d_has);
+        if (d_ns) (void)hipFree(d_ns);
     };
     if ((rc = dev_alloc(h, &d_PT, strm)) || (rc = dev_alloc(h, &d_PN, strm)) || (rc = dev_alloc(h, &d_DT, strm))) { cleanup(); return rc; }
     const int bt = K * K >= 256 ? 256 : 64;
@@ -1885,7 +1932,12 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
 
     /* chunk the site axis so that the stored vectors fit */
-    const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    if (h->prog_dirty) { if ((rc = build_program(h))) { cleanup(); return rc; } }
+    std::vector<int> node_scale(N, -1);
+    int nsc = 0;
+    for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a] && h->scale_node[a]) node_scale[a] = nsc++;
+    if ((rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N))) { cleanup(); return rc; }
+    const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -1905,6 +1957,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
         a.dzero = dzero;
         a.mod_edge = -1; a.DN = nullptr; a.D2T = nullptr; a.LHdiv = nullptr;
+        a.node_scale = d_ns;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
@@ -1912,6 +1965,9 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         a.EV = p; p += (size_t)E * C * k * n;
         a.LN = p; p += (size_t)N * C * k * n;
         a.FN = p; p += (size_t)N * C * k * n;
+        a.SC = p; p += (size_t)nsc * C * n;
+        a.CW = p; p += (size_t)C * n;
+        a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * k * n;
@@ -2337,6 +2393,7 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
         a.dzero = 1;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.DN = d_DN; a.D2T = d_D2T;
+        a.node_scale = nullptr; a.SC = nullptr; a.CW = nullptr; a.XC = nullptr;
         a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = nullptr; a.node_mask = nullptr;
         double *p = h->d_work;

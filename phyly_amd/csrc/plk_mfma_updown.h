@@ -33,7 +33,10 @@ struct MUpArgs {
     const int *edge_mask, *node_mask;
     double *EV, *LN, *FN;         /* [(ent*C + c)*R + r][stride] planes, lane-linear */
     long stride;
-    double *LH;                   /* [n] */
+    const int *node_scale;        /* N: rescaling slot of the node, -1 = not rescaled */
+    double *SC;                   /* [(slot*C + c)][n]: 2^-e applied to L_a at rescaled nodes */
+    double *CW, *XC;              /* [C][n]: 2^(X_c - Xmax); scratch */
+    double *LH;                   /* [n], at the common exponent Xmax */
     double *DV;                   /* [E][n] */
     double *MV;                   /* [N][k][n] */
 };
@@ -115,10 +118,13 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
     const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;
     const int nfrag = T * a.kk4 * 64;
     const int NT = a.ntips + 1;
-    double lh_total = 0.0;
+    const size_t n = (size_t)a.n;
+    const long slc = valid ? sl : a.n - 1;
+    int xmax = INT_MIN;
     for (int c = 0; c < a.C; c++) {
         const double *tipc = a.tip + (size_t)c * NT * a.nchar * 4 * R;
         double lh_c = 0.0;
+        int X = 0;
         for (int u = a.N - 1; u >= 0; u--) {
             const int nd = as_uniform(a.preorder)[u];
             const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
@@ -149,6 +155,24 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
 #pragma unroll
                 for (int r = 0; r < R; r++) acc[r] *= m[r];
             }
+            const int slot = as_uniform(a.node_scale)[nd];
+            if (slot >= 0) {
+                /* exact power-of-two rescaling of the site's vector (its k states live in 4 lanes) */
+                double mx = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; r++) mx = fmax(mx, acc[r]);
+                mx = fmax(mx, __shfl_xor(mx, 16, 64));
+                mx = fmax(mx, __shfl_xor(mx, 32, 64));
+                double sc = 1.0;
+                if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                    const int e = ilogb(mx);
+                    sc = ldexp(1.0, -e);
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r] *= sc;
+                    X += e;
+                }
+                if (valid && g == 0) a.SC[((size_t)slot * a.C + c) * n + sl] = sc;
+            }
             mf_store<R>(a.LN + ((size_t)as_uniform(a.node_int)[nd] * a.C + c) * R * a.stride, a.stride, lin, acc);
             if (u == 0) {
                 const double *rw = a.root_wd + g * R;
@@ -158,9 +182,21 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
                 lh_c += __shfl_xor(lh_c, 32, 64);
             }
         }
-        lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total);
+        lh_c *= as_uniform(a.cat_prior)[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid && g == 0) { a.XC[(size_t)c * n + sl] = (double)X; a.CW[(size_t)c * n + sl] = lh_c; }
     }
-    if (valid && g == 0) a.LH[sl] = lh_total;
+    /* combine the categories at the largest exponent: LH = sum_c prior_c lh_c 2^(X_c - Xmax) */
+    if (xmax == INT_MIN) xmax = 0;
+    if (valid && g == 0) {
+        double lh_total = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + slc] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + slc], w, lh_total);
+            a.CW[(size_t)c * n + slc] = w;
+        }
+        a.LH[sl] = lh_total;
+    }
 }
 
 template <int T, bool DERIV, bool MARG>
@@ -195,7 +231,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
                 double l[R];
                 mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[root] * a.C + c) * R * a.stride, a.stride, lin, l);
 #pragma unroll
-                for (int r = 0; r < R; r++) macc[r] = fma(as_uniform(a.cat_prior)[c] * f[r], l[r], macc[r]);
+                for (int r = 0; r < R; r++) macc[r] = fma(as_uniform(a.cat_prior)[c] * a.CW[(size_t)c * n + slc] * f[r], l[r], macc[r]);
             }
         }
         if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) {
@@ -211,6 +247,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
         if (start == stop) continue;
         const bool has = as_uniform(a.node_has_data)[nd];
         const int chn = has ? a.codes[(size_t)nd * a.Spad + sg] : 0;
+        const int slot = as_uniform(a.node_scale)[nd];
         for (int idx = start; idx < stop; idx++) {
             const int b = as_uniform(a.indices)[idx];
             const bool b_leaf = as_uniform(a.edge_tip)[idx] >= 0;
@@ -233,6 +270,13 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
 #pragma unroll
                     for (int r = 0; r < R; r++) fe[r] *= bn[r];
                 }
+                if (slot >= 0) {
+                    /* the forward vector below a rescaled node carries that node's factor (L_a was scaled after
+                     * the child messages were multiplied in) */
+                    const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+#pragma unroll
+                    for (int r = 0; r < R; r++) fe[r] *= sc;
+                }
                 for (int idx2 = start; idx2 < stop; idx2++) {
                     if (idx2 == idx) continue;
                     double ev[R];
@@ -243,7 +287,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
 #pragma unroll
                     for (int r = 0; r < R; r++) fe[r] *= ev[r];
                 }
-                const double prior = as_uniform(a.cat_prior)[c];
+                const double prior = as_uniform(a.cat_prior)[c] * a.CW[(size_t)c * n + slc];
                 if (want_d) {
                     double y[R];
                     if (b_leaf) {

@@ -135,3 +135,39 @@ def test_deep_tree_rescaling_k4(eng, oracle):
     wantx = oracle.site_edge_expect(m, ow, B, F, 0, None, precise=2)
     gotx, _ = eng.edge_expect(L, E.COEF_PRIOR)
     assert _row_err(gotx, wantx) <= 1e-12
+
+
+def test_deep_tree_rescaling_generic_and_mfma(eng, oracle):
+    """the same property for the other two kernel families: the vector kernels (dense observations, k = 4,
+    1200 taxa) and the matrix-core kernels (k = 20, 400 taxa: site likelihoods ~ 20^-400)"""
+    from phyly_amd import synth
+    w = synth.Workload(T=1200, k=4, tree="yule", model="hky85", seed=79)
+    w.setup_engine(eng)
+    S = 24
+    codes = w.simulate(S)
+    m, ow = oracle_model(oracle, w, codes)
+    B = _dense_from_codes(w, codes)
+    eng.set_patterns_dense(np.ascontiguousarray(B.transpose(1, 2, 0)))
+    eng.set_site_weights(None)
+    ll, _ = eng.ll()
+    assert np.sum(ll < -745.0) >= 10
+    got, _ = eng.deriv()
+    assert np.all(np.isfinite(got))
+    assert _row_err(got, oracle.site_deriv(m, ow, B, precise=2)) <= 1e-12
+    gotm, _ = eng.marginal()
+    assert np.max(np.abs(gotm - oracle.site_marginal(m, ow, B, precise=2))) <= 1e-12
+
+    w = synth.Workload(T=400, k=20, tree="yule", model="aa20", seed=80)
+    w.setup_engine(eng)
+    S = 8
+    codes = w.random_codes(S, seed=3, missing_frac=0.0)      # unrelated states at the tips: ll ~ -3 per taxon
+    m, ow = oracle_model(oracle, w, codes)
+    B = _dense_from_codes(w, codes)
+    eng.set_patterns_codes(codes, w.defs)
+    ll, _ = eng.ll()
+    assert ll.max() < -745.0
+    got, _ = eng.deriv()
+    assert np.all(np.isfinite(got))
+    assert _row_err(got, oracle.site_deriv(m, ow, B, precise=2)) <= 1e-12
+    gotm, _ = eng.marginal()
+    assert np.max(np.abs(gotm - oracle.site_marginal(m, ow, B, precise=2))) <= 1e-12
