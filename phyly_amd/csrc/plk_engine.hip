@@ -1293,7 +1293,7 @@ static int build_program(plk_engine *h)
                 continue;
             }
             if (h->node_has_data[a]) { emit(OP_NODE_MUL, 0, a, -1); obs(a); }
-            if (scale_here[a]) emit(OP_SCALE, 0, 0, -1);
+            if (scale_here[a]) emit(OP_SCALE, 0, a, -1);   /* y = the node (used by the storing down pass) */
             stk.pop_back();
         }
     }
@@ -1797,16 +1797,18 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr, *d_ns = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr, *d_oe2 = nullptr;
+    int2 *d_ops2 = nullptr;
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_tip4, d_dtip4};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_ops2, d_tip4, d_dtip4};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)std::max(E, 1))) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)std::max(E, 1))) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
         (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
+        (rc = dev_upload(h, &d_ops2, h->ops.data(), h->ops.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
         (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
     if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
@@ -1853,7 +1855,10 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
-        hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        if (d_ops2 && h->slots_needed <= 4) hipLaunchKernelGGL(k_down_fused4<4>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
+        else if (d_ops2 && h->slots_needed <= 8) hipLaunchKernelGGL(k_down_fused4<8>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
+        else if (d_ops2 && h->slots_needed <= 16) hipLaunchKernelGGL(k_down_fused4<16>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
+        else hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv) hipLaunchKernelGGL((k_up4<true, false>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else hipLaunchKernelGGL((k_up4<false, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);

@@ -158,6 +158,87 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
     }
 }
 
+/*
+ * The same down pass as a depth-first traversal of the post-order program (OP_* of plk_engine.hip): the vector
+ * under construction stays in registers, vectors waiting for a sibling subtree are parked in AGPRs (as in the
+ * fused ll kernels), so every internal node vector is written once and never read back here -- half the HBM
+ * traffic of k_down_store4.  A node's vector is final when its parent multiplies it by P (OP_MATVEC) or, for the
+ * root, when the program ends.
+ */
+template <int D>
+__global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int2 *ops_, const int *op_edge_, int nops)
+{
+    if constexpr (D <= 4) asm volatile("" ::: PLK_CLOBBER_A0_31);
+    else if constexpr (D <= 8) asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
+    else asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);
+    const long sl = (long)blockIdx.x * UD4_BLOCK + threadIdx.x;
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const size_t n = (size_t)a.n;
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(ops_)), *oe = as_uniform(op_edge_);
+    const PLK_AS4 int *ix = as_uniform(a.indices), *nint = as_uniform(a.node_int), *nsc = as_uniform(a.node_scale);
+    const PLK_AS4 double *Pm = as_uniform(a.P), *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
+    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
+    const int root = as_uniform(a.preorder)[0];
+    int xmax = INT_MIN;
+    for (int c = 0; c < a.C; c++) {
+        const double *tipc = a.tip + (size_t)c * tabc;
+        v4 cur = v4{1.0, 1.0, 1.0, 1.0};
+        int X = 0;
+        for (int pc = 0; pc < nops; pc++) {
+            const int ox = ops[2 * pc], oy = ops[2 * pc + 1];
+            const int code = ox & 0xff;
+            if (code == OP_MATVEC) {
+                const int e = oe[pc];
+                if (valid) st4(a.LN + (((size_t)nint[ix[e]] * a.C + c) * n + slc) * 4, cur);
+                v4 m = mv4(Pm + ((size_t)c * a.E + e) * 16, cur);
+                if (const4(cur)) m = cur;
+                cur = m;
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
+                const v4 v = ld4(tipc + ((size_t)t * a.nchar + a.codes[(size_t)oy * a.Spad + sg]) * 4);
+                cur = code == OP_TIP_SET ? v : mul4(cur, v);
+            } else if (code == OP_PUSH) {
+                stack_push<D, 1>(oy, 0, cur.a, cur.b, cur.c, cur.d);
+            } else if (code == OP_POPMUL) {
+                stack_popmul<D, 1>(oy, 0, cur.a, cur.b, cur.c, cur.d);
+            } else if (code == OP_SCALE) {
+                const int slot = nsc[oy];
+                if (slot >= 0) {
+                    const double mx = fmax(fmax(cur.a, cur.b), fmax(cur.c, cur.d));
+                    double sc = 1.0;
+                    if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                        const int ex = ilogb(mx);
+                        sc = ldexp(1.0, -ex);
+                        cur.a *= sc; cur.b *= sc; cur.c *= sc; cur.d *= sc;
+                        X += ex;
+                    }
+                    if (valid) a.SC[((size_t)slot * a.C + c) * n + slc] = sc;
+                }
+            }
+        }
+        if (valid) st4(a.LN + (((size_t)nint[root] * a.C + c) * n + slc) * 4, cur);
+        double lh_c;
+        if (a.root_mode == PLK_ROOT_NONE) lh_c = ((cur.a + cur.b) + cur.c) + cur.d;
+        else if (a.root_mode == PLK_ROOT_UNIFORM) lh_c = (((cur.a + cur.b) + cur.c) + cur.d) * 0.25;
+        else lh_c = fma(rw[3], cur.d, fma(rw[2], cur.c, fma(rw[1], cur.b, rw[0] * cur.a)));
+        lh_c *= prior[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid) { a.XC[(size_t)c * n + slc] = (double)X; a.CW[(size_t)c * n + slc] = lh_c; }
+    }
+    if (xmax == INT_MIN) xmax = 0;
+    if (valid) {
+        double lh_total = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + slc] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + slc], w, lh_total);
+            a.CW[(size_t)c * n + slc] = w;
+        }
+        a.LH[sl] = lh_total;
+    }
+}
+
 /* per-child state of the up pass */
 struct Ud4Child {
     int idx, b, t, code;
