@@ -1797,18 +1797,47 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr, *d_ns = nullptr, *d_oe2 = nullptr;
-    int2 *d_ops2 = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr, *d_oe2 = nullptr, *d_obs2 = nullptr;
+    int4 *d_ops2 = nullptr;
+    /* down-pass program: observation ops carry their staged code row and the (slot, row) of the next one */
+    std::vector<int4> ops2(h->ops.size() + 1);
+    { int4 e4; e4.x = OP_END; e4.y = e4.z = e4.w = 0; ops2.back() = e4; }      /* read one op ahead */
+    int first_slot2 = -1, first_row2 = 0;
+    const int nobs2 = (int)h->obs_nodes.size();
+    {
+        std::vector<int> row(N, -1);
+        for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
+        int prev = -1;
+        for (size_t pc = 0; pc < h->ops.size(); pc++) {
+            const int code = h->ops[pc].x & 0xff;
+            int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
+            if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int slot = code == OP_NODE_MUL ? ntips : (o.x >> 8);
+                o.y = row[h->ops[pc].y];
+                if (prev < 0) { first_slot2 = slot; first_row2 = o.y; }
+                else { ops2[prev].z = slot; ops2[prev].w = o.y; }
+                prev = (int)pc;
+            } else if (code == OP_MATVEC) {
+                o.y = h->op_edge[pc];
+                o.z = node_int[h->indices[h->op_edge[pc]]];
+            } else if (code == OP_SCALE) {
+                o.y = node_scale[h->ops[pc].y];
+            }
+            ops2[pc] = o;
+        }
+        if (prev >= 0) { ops2[prev].z = first_slot2 | (1 << 30); ops2[prev].w = first_row2; }
+    }
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_ops2, d_tip4, d_dtip4};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_obs2, d_ops2, d_tip4, d_dtip4};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)std::max(E, 1))) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)std::max(E, 1))) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
         (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
-        (rc = dev_upload(h, &d_ops2, h->ops.data(), h->ops.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
+        (rc = dev_upload(h, &d_ops2, ops2.data(), ops2.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
+        (rc = dev_upload(h, &d_obs2, h->obs_nodes.data(), h->obs_nodes.size())) ||
         (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
     if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
@@ -1855,9 +1884,11 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
-        if (d_ops2 && h->slots_needed <= 4) hipLaunchKernelGGL(k_down_fused4<4>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
-        else if (d_ops2 && h->slots_needed <= 8) hipLaunchKernelGGL(k_down_fused4<8>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
-        else if (d_ops2 && h->slots_needed <= 16) hipLaunchKernelGGL(k_down_fused4<16>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a, d_ops2, d_oe2, (int)h->ops.size());
+        const size_t lds_codes = (size_t)nobs2 * UD4_BLOCK;
+        const bool fused_ok = d_ops2 && lds_codes <= 60 * 1024 && (s0 % UD4_BLOCK) == 0;
+        if (fused_ok && h->slots_needed <= 4) hipLaunchKernelGGL(k_down_fused4<4>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
+        else if (fused_ok && h->slots_needed <= 8) hipLaunchKernelGGL(k_down_fused4<8>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
+        else if (fused_ok && h->slots_needed <= 16) hipLaunchKernelGGL(k_down_fused4<16>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
         else hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv) hipLaunchKernelGGL((k_up4<true, false>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);

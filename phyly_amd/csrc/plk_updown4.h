@@ -166,46 +166,68 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_store4(Up4Args a)
  * root, when the program ends.
  */
 template <int D>
-__global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int2 *ops_, const int *op_edge_, int nops)
+__global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int4 *ops_, const int *op_edge_, int nops,
+                                                           const int *obs_nodes, int nobs, int first_slot, int first_row)
 {
     if constexpr (D <= 4) asm volatile("" ::: PLK_CLOBBER_A0_31);
     else if constexpr (D <= 8) asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
     else asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);
-    const long sl = (long)blockIdx.x * UD4_BLOCK + threadIdx.x;
+    extern __shared__ uint8_t ud4_codes[];            /* nobs x 256 pattern codes of this block's sites */
+    const int tid = threadIdx.x;
+    const long sl = (long)blockIdx.x * UD4_BLOCK + tid;
     const bool valid = sl < a.n;
     const long slc = valid ? sl : a.n - 1;
-    const long sg = a.s0 + slc;
     const size_t n = (size_t)a.n;
-    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(ops_)), *oe = as_uniform(op_edge_);
-    const PLK_AS4 int *ix = as_uniform(a.indices), *nint = as_uniform(a.node_int), *nsc = as_uniform(a.node_scale);
+    {
+        /* rows are padded to Spad (a multiple of 1024) and chunks start at multiples of 256 */
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ud4_codes);
+        for (int idx = tid; idx < nobs * (UD4_BLOCK / 4); idx += UD4_BLOCK) {
+            const int row = idx / (UD4_BLOCK / 4), col = idx - row * (UD4_BLOCK / 4);
+            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)obs_nodes[row] * a.Spad + a.s0 +
+                                                          (size_t)blockIdx.x * UD4_BLOCK)[col];
+        }
+    }
+    __syncthreads();
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(ops_));
+    const PLK_AS4 int *nint = as_uniform(a.node_int);
     const PLK_AS4 double *Pm = as_uniform(a.P), *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
     const int root = as_uniform(a.preorder)[0];
+    (void)op_edge_;
     int xmax = INT_MIN;
+    /* observation values are gathered one observation op ahead (the code comes from LDS, so the address of the
+     * next gather is known as soon as the current op starts) */
+    v4 nxt = v4{1.0, 1.0, 1.0, 1.0};
+    if (first_slot >= 0) nxt = ld4(a.tip + ((size_t)first_slot * a.nchar + ud4_codes[first_row * UD4_BLOCK + tid]) * 4);
     for (int c = 0; c < a.C; c++) {
-        const double *tipc = a.tip + (size_t)c * tabc;
         v4 cur = v4{1.0, 1.0, 1.0, 1.0};
         int X = 0;
+        /* op words are fetched one op ahead (the program is padded with one OP_END) */
+        int nx = ops[0], ny = ops[1], nz = ops[2], nw = ops[3];
         for (int pc = 0; pc < nops; pc++) {
-            const int ox = ops[2 * pc], oy = ops[2 * pc + 1];
+            const int ox = nx, oy = ny, oz = nz, ow = nw;
+            nx = ops[4 * pc + 4]; ny = ops[4 * pc + 5]; nz = ops[4 * pc + 6]; nw = ops[4 * pc + 7];
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
-                const int e = oe[pc];
-                if (valid) st4(a.LN + (((size_t)nint[ix[e]] * a.C + c) * n + slc) * 4, cur);
-                v4 m = mv4(Pm + ((size_t)c * a.E + e) * 16, cur);
+                /* y = CSR edge, z = storage index of the child node whose vector is now final */
+                if (valid) st4(a.LN + (((size_t)oz * a.C + c) * n + slc) * 4, cur);
+                v4 m = mv4(Pm + ((size_t)c * a.E + oy) * 16, cur);
                 if (const4(cur)) m = cur;
                 cur = m;
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
-                const v4 v = ld4(tipc + ((size_t)t * a.nchar + a.codes[(size_t)oy * a.Spad + sg]) * 4);
+                const v4 v = nxt;
+                const int wrap = (oz >> 30) & 1;
+                if (!wrap || c + 1 < a.C)
+                    nxt = ld4(a.tip + (size_t)(c + wrap) * tabc +
+                              ((size_t)(oz & 0x3fffffff) * a.nchar + ud4_codes[ow * UD4_BLOCK + tid]) * 4);
                 cur = code == OP_TIP_SET ? v : mul4(cur, v);
             } else if (code == OP_PUSH) {
                 stack_push<D, 1>(oy, 0, cur.a, cur.b, cur.c, cur.d);
             } else if (code == OP_POPMUL) {
                 stack_popmul<D, 1>(oy, 0, cur.a, cur.b, cur.c, cur.d);
             } else if (code == OP_SCALE) {
-                const int slot = nsc[oy];
-                if (slot >= 0) {
+                /* y = rescaling slot of the node (-1: none) */
+                if (oy >= 0) {
                     const double mx = fmax(fmax(cur.a, cur.b), fmax(cur.c, cur.d));
                     double sc = 1.0;
                     if (mx > 0x1p-1000 && mx < 0x1p+1000) {
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int2
                         cur.a *= sc; cur.b *= sc; cur.c *= sc; cur.d *= sc;
                         X += ex;
                     }
-                    if (valid) a.SC[((size_t)slot * a.C + c) * n + slc] = sc;
+                    if (valid) a.SC[((size_t)oy * a.C + c) * n + slc] = sc;
                 }
             }
         }
