@@ -1799,6 +1799,21 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
     int *d_has = nullptr, *d_ns = nullptr, *d_oe2 = nullptr, *d_obs2 = nullptr;
     int4 *d_ops2 = nullptr;
+    /* nodes the up pass handles inside their parent's visit (see Up4Args.node_inline) */
+    std::vector<int> node_inline(N, 0);
+    int *d_inl = nullptr;
+    for (int p = 0; p < N; p++) {
+        const int pdeg = h->indptr[p + 1] - h->indptr[p];
+        if (pdeg < 1 || pdeg > 2) continue;
+        for (int idx = h->indptr[p]; idx < h->indptr[p + 1]; idx++) {
+            const int b = h->indices[idx];
+            const int bdeg = h->indptr[b + 1] - h->indptr[b];
+            if (bdeg < 1 || bdeg > 2) continue;
+            bool all_leaves = true;
+            for (int j = h->indptr[b]; j < h->indptr[b + 1]; j++) all_leaves = all_leaves && edge_tip[j] >= 0;
+            if (all_leaves) node_inline[b] = 1;
+        }
+    }
     /* down-pass program: observation ops carry their staged code row and the (slot, row) of the next one */
     std::vector<int4> ops2(h->ops.size() + 1);
     { int4 e4; e4.x = OP_END; e4.y = e4.z = e4.w = 0; ops2.back() = e4; }      /* read one op ahead */
@@ -1829,7 +1844,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     }
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_obs2, d_ops2, d_tip4, d_dtip4};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_obs2, d_ops2, d_inl, d_tip4, d_dtip4};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
@@ -1838,6 +1853,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
         (rc = dev_upload(h, &d_ops2, ops2.data(), ops2.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
         (rc = dev_upload(h, &d_obs2, h->obs_nodes.data(), h->obs_nodes.size())) ||
+        (rc = dev_upload(h, &d_inl, node_inline.data(), (size_t)N)) ||
         (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
     if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
@@ -1869,7 +1885,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.N = N; a.E = E; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode;
         a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
-        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni; a.node_scale = d_ns;
+        a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni; a.node_scale = d_ns; a.node_inline = d_inl;
         a.P = h->d_P; a.dP = d_M; a.tip = d_tip4; a.dtip = d_dtip4;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
         double *p = h->d_work;

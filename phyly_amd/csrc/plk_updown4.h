@@ -36,6 +36,9 @@ struct Up4Args {
     const double *cat_prior, *root_w;
     const int *edge_mask, *node_mask;
     const int *node_scale;         /* N: index of the node's rescaling slot, -1 = not rescaled */
+    const int *node_inline;        /* N: 1 = all children are leaves (at most two) and the parent has at most two
+                                      children: the up pass handles the node inside its parent's visit, so its
+                                      forward vector is never stored */
     double *LN, *FN;               /* [(ent*C + c)][n][4] */
     double *SC;                    /* [(slot*C + c)][n]: 2^-e applied to L_a at rescaled nodes */
     double *CW, *XC;               /* [C][n]: 2^(X_c - Xmax); scratch: X_c and category likelihood mantissas */
@@ -277,6 +280,87 @@ __device__ static inline Ud4Child ud4_child(const Up4Args &a, int idx, long sg)
     return ch;
 }
 
+
+/* an internal node whose (one or two) children are all leaves, handled inside its parent's visit */
+struct Ud4Pre {
+    int deg, idx0, idx1, t0, t1, cd0, cd1, b0, b1, chn, slot;
+    bool hd, wd0, wd1, wm0, wm1;
+};
+
+template <bool DERIV, bool MARG>
+__device__ static inline Ud4Pre ud4_pre(const Up4Args &a, int b, long sg)
+{
+    Ud4Pre q;
+    const int start = as_uniform(a.indptr)[b];
+    q.deg = as_uniform(a.indptr)[b + 1] - start;
+    q.idx0 = start; q.idx1 = q.deg == 2 ? start + 1 : start;
+    q.b0 = as_uniform(a.indices)[q.idx0]; q.b1 = as_uniform(a.indices)[q.idx1];
+    q.t0 = as_uniform(a.edge_tip)[q.idx0]; q.t1 = as_uniform(a.edge_tip)[q.idx1];
+    q.cd0 = a.codes[(size_t)q.b0 * a.Spad + sg];
+    q.cd1 = a.codes[(size_t)q.b1 * a.Spad + sg];
+    q.hd = as_uniform(a.node_has_data)[b] != 0;
+    q.chn = q.hd ? a.codes[(size_t)b * a.Spad + sg] : 0;
+    q.slot = as_uniform(a.node_scale)[b];
+    q.wd0 = DERIV && (!a.edge_mask || as_uniform(a.edge_mask)[q.idx0]);
+    q.wd1 = DERIV && q.deg == 2 && (!a.edge_mask || as_uniform(a.edge_mask)[q.idx1]);
+    q.wm0 = MARG && (!a.node_mask || as_uniform(a.node_mask)[q.b0]);
+    q.wm1 = MARG && q.deg == 2 && (!a.node_mask || as_uniform(a.node_mask)[q.b1]);
+    return q;
+}
+
+/* one category of such a node: fb is its forward vector */
+__device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double *tipc, const double *dtipc,
+                                           const PLK_AS4 double *Pm, double pc, size_t n, long slc, const v4 &fb,
+                                           const Ud4Pre &q, double &pd0, double &pd1, v4 &pm0, v4 &pm1)
+{
+    v4 g = fb;
+    if (q.hd) g = mul4(g, ld4(tipc + ((size_t)a.ntips * a.nchar + q.chn) * 4));
+    if (q.slot >= 0) {
+        const double sc = a.SC[((size_t)q.slot * a.C + c) * n + slc];
+        g.a *= sc; g.b *= sc; g.c *= sc; g.d *= sc;
+    }
+    v4 fe0 = g, fe1 = g;
+    if (q.deg == 2) {
+        fe0 = mul4(g, ld4(tipc + ((size_t)q.t1 * a.nchar + q.cd1) * 4));
+        fe1 = mul4(g, ld4(tipc + ((size_t)q.t0 * a.nchar + q.cd0) * 4));
+    }
+    if (q.wd0) {
+        const v4 y = ld4(dtipc + ((size_t)q.t0 * a.nchar + q.cd0) * 4);
+        pd0 = fma(pc, fma(fe0.d, y.d, fma(fe0.c, y.c, fma(fe0.b, y.b, fe0.a * y.a))), pd0);
+    }
+    if (q.wd1) {
+        const v4 y = ld4(dtipc + ((size_t)q.t1 * a.nchar + q.cd1) * 4);
+        pd1 = fma(pc, fma(fe1.d, y.d, fma(fe1.c, y.c, fma(fe1.b, y.b, fe1.a * y.a))), pd1);
+    }
+    if (q.wm0) {
+        const v4 f = mtv4(Pm + ((size_t)c * a.E + q.idx0) * 16, fe0);
+        const v4 lb = ld4(tipc + ((size_t)a.ntips * a.nchar + q.cd0) * 4);
+        pm0.a = fma(pc * f.a, lb.a, pm0.a); pm0.b = fma(pc * f.b, lb.b, pm0.b);
+        pm0.c = fma(pc * f.c, lb.c, pm0.c); pm0.d = fma(pc * f.d, lb.d, pm0.d);
+    }
+    if (q.wm1) {
+        const v4 f = mtv4(Pm + ((size_t)c * a.E + q.idx1) * 16, fe1);
+        const v4 lb = ld4(tipc + ((size_t)a.ntips * a.nchar + q.cd1) * 4);
+        pm1.a = fma(pc * f.a, lb.a, pm1.a); pm1.b = fma(pc * f.b, lb.b, pm1.b);
+        pm1.c = fma(pc * f.c, lb.c, pm1.c); pm1.d = fma(pc * f.d, lb.d, pm1.d);
+    }
+}
+
+__device__ static inline void ud4_pre_write(const Up4Args &a, size_t n, long sl, double inv, const Ud4Pre &q,
+                                            double pd0, double pd1, const v4 &pm0, const v4 &pm1)
+{
+    if (q.wd0) a.DV[(size_t)q.idx0 * n + sl] = pd0 * inv;
+    if (q.wd1) a.DV[(size_t)q.idx1 * n + sl] = pd1 * inv;
+    if (q.wm0) {
+        double *mv = a.MV + (size_t)q.b0 * 4 * n + sl;
+        mv[0] = pm0.a * inv; mv[n] = pm0.b * inv; mv[2 * n] = pm0.c * inv; mv[3 * n] = pm0.d * inv;
+    }
+    if (q.wm1) {
+        double *mv = a.MV + (size_t)q.b1 * 4 * n + sl;
+        mv[0] = pm1.a * inv; mv[n] = pm1.b * inv; mv[2 * n] = pm1.c * inv; mv[3 * n] = pm1.d * inv;
+    }
+}
+
 template <bool DERIV, bool MARG>
 __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
 {
@@ -318,7 +402,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
         const int nd = pre[u];
         const int start = ip[nd], stop = ip[nd + 1];
         const int deg = stop - start;
-        if (deg == 0) continue;
+        if (deg == 0 || as_uniform(a.node_inline)[nd]) continue;
         const bool hd = has[nd] != 0;
         const int chn = hd ? a.codes[(size_t)nd * a.Spad + sg] : 0;
         const int slot = nsc[nd];
@@ -335,8 +419,16 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
             c1.want_f = deg == 2 && (c1.t < 0 || c1.want_m);
             double d0 = 0.0, d1 = 0.0;
             v4 m0 = zero, m1 = zero;
+            const bool in0 = c0.t < 0 && as_uniform(a.node_inline)[c0.b];
+            const bool in1 = deg == 2 && c1.t < 0 && as_uniform(a.node_inline)[c1.b];
+            Ud4Pre q0 = {}, q1 = {};
+            if (in0) q0 = ud4_pre<DERIV, MARG>(a, c0.b, sg);
+            if (in1) q1 = ud4_pre<DERIV, MARG>(a, c1.b, sg);
+            double p00 = 0.0, p01 = 0.0, p10 = 0.0, p11 = 0.0;
+            v4 r00 = zero, r01 = zero, r10 = zero, r11 = zero;
             for (int c = 0; c < a.C; c++) {
                 const double *tipc = a.tip + (size_t)c * tabc;
+                const double *dtipc = a.dtip + (size_t)c * tabc;
                 v4 g = ld4(fn_nd + ((size_t)c * n + slc) * 4);
                 if (hd) g = mul4(g, ld4(tipc + ((size_t)a.ntips * a.nchar + chn) * 4));
                 if (slot >= 0) {
@@ -352,7 +444,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                     fe0 = mul4(g, ud4_child_msg(a, c, c1.idx, c1.t, c1.code, tipc, Pm, x1));
                     fe1 = mul4(g, ud4_child_msg(a, c, c0.idx, c0.t, c0.code, tipc, Pm, x0));
                 }
-#define UD4_EDGE(CH, FE, X, DS, MS)                                                                         \
+#define UD4_EDGE(CH, FE, X, DS, MS, INL, Q, PA, PB, RA, RB)                                                 \
                 if (CH.want_d) {                                                                            \
                     v4 y;                                                                                   \
                     if (CH.t >= 0) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)CH.t * a.nchar + CH.code) * 4); \
@@ -364,18 +456,21 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                 }                                                                                           \
                 if (CH.want_f) {                                                                            \
                     const v4 fb = mtv4(Pm + ((size_t)c * a.E + CH.idx) * 16, FE);                           \
-                    if (CH.t < 0 && valid) st4(a.FN + (((size_t)nint[CH.b] * a.C + c) * n + slc) * 4, fb);  \
+                    if (INL) ud4_pre_step(a, c, tipc, dtipc, Pm, pc, n, slc, fb, Q, PA, PB, RA, RB);        \
+                    else if (CH.t < 0 && valid) st4(a.FN + (((size_t)nint[CH.b] * a.C + c) * n + slc) * 4, fb);  \
                     if (CH.want_m) {                                                                        \
                         const v4 lb = CH.t >= 0 ? ld4(tipc + ((size_t)a.ntips * a.nchar + CH.code) * 4) : X; \
                         MS.a = fma(pc * fb.a, lb.a, MS.a); MS.b = fma(pc * fb.b, lb.b, MS.b);               \
                         MS.c = fma(pc * fb.c, lb.c, MS.c); MS.d = fma(pc * fb.d, lb.d, MS.d);               \
                     }                                                                                       \
                 }
-                UD4_EDGE(c0, fe0, x0, d0, m0)
-                if (deg == 2) { UD4_EDGE(c1, fe1, x1, d1, m1) }
+                UD4_EDGE(c0, fe0, x0, d0, m0, in0, q0, p00, p01, r00, r01)
+                if (deg == 2) { UD4_EDGE(c1, fe1, x1, d1, m1, in1, q1, p10, p11, r10, r11) }
 #undef UD4_EDGE
             }
             if (valid) {
+                if (in0) ud4_pre_write(a, n, sl, inv, q0, p00, p01, r00, r01);
+                if (in1) ud4_pre_write(a, n, sl, inv, q1, p10, p11, r10, r11);
                 if (c0.want_d) a.DV[(size_t)c0.idx * n + sl] = d0 * inv;
                 if (c1.want_d) a.DV[(size_t)c1.idx * n + sl] = d1 * inv;
                 if (c0.want_m) {
