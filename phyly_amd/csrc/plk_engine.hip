@@ -1568,8 +1568,8 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double) + (size_t)a.nobs * MF_SITES;
         if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
-        else if (T == 3) hipLaunchKernelGGL(k_ll_mfma<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
-        else hipLaunchKernelGGL(k_ll_mfma<4>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else if (T == 3) hipLaunchKernelGGL(k_ll_mfma_occ4<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else hipLaunchKernelGGL(k_ll_mfma_occ4<4>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         h->info_ll_kernel = 3;
     } else {
         grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);

@@ -47,7 +47,7 @@ struct MfmaArgs {
 };
 
 template <int T>
-__global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
+__device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
 {
     extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles, then nobs x 64 staged pattern codes */
     constexpr int R = 4 * T;                      /* registers (states) per lane */
@@ -170,6 +170,14 @@ __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a)
         if (tid == 0) a.partial[blockIdx.x] = r;
     }
 }
+
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a) { ll_mfma_body<T>(a); }
+
+/* the same kernel compiled for 4 waves per SIMD (<= 128 registers): +25 % at k = 61 (T = 4), where the default
+ * allocation of 160 registers leaves 3 waves; slower at T = 2, which already fits */
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ll_mfma_occ4(MfmaArgs a) { ll_mfma_body<T>(a); }
 
 /* A fragments: frag[((c*nops + pc)*T + t)*kk4 + q][l] = P[c][edge(pc)][16t + (l&15)][4q + (l>>4)] */
 __global__ void k_build_frag(int k, int T, int kk4, int E, int nops, const int *__restrict__ op_edge,

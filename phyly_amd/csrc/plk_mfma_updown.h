@@ -107,7 +107,7 @@ __device__ static inline void mf_stage(double *lds_frag, const double *src, int 
 }
 
 template <int T>
-__global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_down_store_mfma(MUpArgs a)
 {
     extern __shared__ double lds_frag[];
     constexpr int R = 4 * T;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_down_store_mfma(MUpArgs a)
 }
 
 template <int T, bool DERIV, bool MARG>
-__global__ __launch_bounds__(MF_BLOCK) void k_up_mfma(MUpArgs a)
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_up_mfma(MUpArgs a)
 {
     extern __shared__ double lds_frag[];
     constexpr int R = 4 * T;
