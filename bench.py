@@ -153,13 +153,13 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma"}.get(kernel_kind, "?")
+        kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
         hbm_model = dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=hbm_equiv / HBM_PEAK,
                          note="A_ll=%d B/site of the HBM-resident-partials design (SURVEY.md 8d)" % alg["A_ll"])
         # which roof binds the kernel that ran: the fused and the matrix-core kernels keep the
         # partial vectors out of HBM (compulsory traffic N+8 B/site), so fp64 arithmetic binds them;
         # the generic vector kernel streams its stack slots through HBM.
-        fp64_bound = kernel_kind in (1, 3) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
+        fp64_bound = kernel_kind in (1, 3, 4) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
         if fp64_bound:
             roofline = dict(bound="mfma", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
                             frac=flops / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,

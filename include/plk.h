@@ -181,7 +181,8 @@ int plk_hess(plk_engine *h, double *hess_sums_out);
 int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
 int plk_get_info(plk_engine *h, int what, long *out);
 enum {
-    PLK_INFO_LL_KERNEL = 0,       /* 0 = none yet, 1 = fused register-stack (k=4), 2 = generic vector, 3 = fp64 MFMA */
+    PLK_INFO_LL_KERNEL = 0,       /* 0 = none yet, 1 = fused register-stack (k=4), 2 = generic vector, 3 = fp64 MFMA,
+                                     4 = register-resident vector kernel (9 <= k <= 32) */
     PLK_INFO_STACK_SLOTS = 1,     /* register-stack slots the tree needs */
     PLK_INFO_PROGRAM_OPS = 2,     /* ops in the traversal program */
     PLK_INFO_LAST_LL_KERNEL_NS = 3, /* HIP-event time of the last ll traversal kernel */
@@ -193,7 +194,8 @@ enum {
 int plk_set_option(plk_engine *h, int option, long value);
 enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PER_LANE = 2 /* 0 auto, 1, 2 */,
        PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */,
-       PLK_OPT_MFMA = 4 /* 1 (default): fp64 matrix-core kernel for 9 <= k <= 64, 0: vector kernel */ };
+       PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
+                           33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */ };
 
 #ifdef __cplusplus
 }

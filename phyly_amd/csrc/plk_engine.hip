@@ -432,6 +432,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 #include "plk_fused4_asm2.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
+#include "plk_vec.h"
 #include "plk_updown4.h"
 
 /* ====================================================================== */
@@ -1314,6 +1315,13 @@ static int fused_sites_per_lane(const plk_engine *h)
     return 1;   /* the assembly interpreter (one site per lane) is the fastest variant measured */
 }
 
+/* register-resident vector kernel (plk_vec.h): 9 <= k <= 32 with compact codes (amino acids); PLK_OPT_MFMA = 2
+ * forces the matrix-core kernel instead */
+static bool use_vec(const plk_engine *h)
+{
+    return !h->opt_force_generic && h->opt_mfma == 1 && h->pat_mode == 1 && h->k >= 9 && h->k <= 32;
+}
+
 /* fp64 matrix-core kernel: larger state spaces with compact codes */
 static bool use_mfma(const plk_engine *h)
 {
@@ -1457,7 +1465,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
     const bool fused = use_fused(h);
-    const long kind = fused ? 1 : (use_mfma(h) ? 3 : 2);
+    const long kind = fused ? 1 : (use_vec(h) ? 4 : (use_mfma(h) ? 3 : 2));
     if (h->stream_dirty || kind != h->info_ll_kernel) {
         h->stream_dirty = true;
         h->mfma_dirty = true;
@@ -1509,6 +1517,33 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
             else launch_fused<16, 1>(h, a, grid, lds);
         }
         h->info_ll_kernel = 1;
+    } else if (use_vec(h)) {
+        /* 9 <= k <= 32 with compact codes: register-resident vector kernel (plk_vec.h) */
+        const int K = h->K, nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
+        grid = (unsigned)((S + VEC_BLOCK - 1) / VEC_BLOCK);
+        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        const int nslots = std::max(h->slots_needed, 1);
+        if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * K * S))) return rc;
+        if (h->mfma_dirty) {
+            std::vector<int> te = h->tip_edge;
+            te.push_back(-1);
+            if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
+            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * K))) return rc;
+            hipLaunchKernelGGL(k_build_tip_vec, dim3(ntips + 1, h->C), dim3(256), 0, h->stream,
+                               h->k, K, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+            HIPCHK(h, hipGetLastError());
+            h->mfma_dirty = false;
+        }
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        VecArgs a;
+        a.S = S; a.Spad = h->Spad; a.k = h->k; a.C = h->C; a.nops = nops; a.ntips = ntips; a.nchar = h->nchar;
+        a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS; a.tip = h->d_tip; a.codes = h->d_codes;
+        a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
+        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        if (K == 16) hipLaunchKernelGGL(k_ll_vec<16>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        else if (K == 20) hipLaunchKernelGGL(k_ll_vec<20>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        else hipLaunchKernelGGL(k_ll_vec<32>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        h->info_ll_kernel = 4;
     } else if (use_mfma(h)) {
         /* 9 <= k <= 64 with compact codes: fp64 matrix-core kernel (plk_mfma.h) */
         const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;

@@ -1,0 +1,158 @@
+/*
+ * plk_vec.h -- K2+K3 for medium state spaces (9 <= k <= 32: amino acids) on the vector fp64 pipe.
+ * Included by plk_engine.hip.
+ *
+ * For k = 20 the 16-row granularity of v_mfma_f64_16x16x4_f64 wastes 37 % of the matrix pipe (20 states padded
+ * to 32 rows) and every product costs two workgroup barriers for the fragment staging; the fp64 vector peak on
+ * MI355X equals the fp64 matrix peak, so a register-resident vector kernel does strictly less work:
+ * one site per lane, the vector under construction in K VGPR pairs, P_e (transposed, in program order, the
+ * stream of the generic kernel) through scalar loads as SGPR operands of v_fma_f64 -- k*k FMAs per product and
+ * no LDS, no barriers.  Leaves use tip tables P_e * defs[code] (double-double built) gathered from L2; vectors
+ * waiting for a sibling subtree live in HBM slots (site fastest).
+ *
+ * Replaces: src/arbplfll.c:139-170 x src/evaluate_site_lhood.c:21-57 x src/util.c:242-301.
+ */
+#ifndef PLK_VEC_H
+#define PLK_VEC_H
+
+#define VEC_BLOCK 256
+
+struct VecArgs {
+    long S, Spad;
+    int k, C, nops, ntips, nchar, root_mode;
+    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot */
+    const double *PS;         /* [C][nops][K*K]: PS[j*K + i] = P[i][j], zero padded */
+    const double *tip;        /* [C][ntips+1][nchar][K]: P_e defs[code]; last slot = the definitions themselves */
+    const uint8_t *codes;     /* [N][Spad] */
+    const double *cat_prior, *root_w, *w;
+    double *slots;            /* [nslots][K][S] */
+    double *site_ll;
+    dd *partial;
+};
+
+template <int K>
+__global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
+{
+    const int tid = threadIdx.x;
+    const long s = (long)blockIdx.x * VEC_BLOCK + tid;
+    const bool valid = s < a.S;
+    const long sc = valid ? s : a.S - 1;
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(a.ops));
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
+    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
+
+    double sum = 0.0;
+    int Eexp = 0;
+    bool have = false;
+    for (int c = 0; c < a.C; c++) {
+        double cur[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) cur[i] = 1.0;
+        int esc = 0;
+        const PLK_AS4 double *PSc = as_uniform(a.PS) + (size_t)c * a.nops * K * K;
+        const double *tipc = a.tip + (size_t)c * tabc;
+        for (int pc = 0; pc < a.nops; pc++) {
+            const int ox = ops[2 * pc], oy = ops[2 * pc + 1];
+            const int code = ox & 0xff;
+            if (code == OP_MATVEC) {
+                const PLK_AS4 double *M = PSc + (size_t)pc * K * K;
+                double acc[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) acc[i] = M[i] * cur[0];
+#pragma unroll
+                for (int j = 1; j < K; j++) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) acc[i] = fma(M[j * K + i], cur[j], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] = acc[i];
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
+                const int ch = a.codes[(size_t)oy * a.Spad + sc];
+                const double2 *tp = reinterpret_cast<const double2 *>(tipc + ((size_t)t * a.nchar + ch) * K);
+                if (code == OP_TIP_SET) {
+#pragma unroll
+                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] = v.x; cur[i + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] *= v.x; cur[i + 1] *= v.y; }
+                }
+            } else if (code == OP_PUSH) {
+                double *sp = a.slots + (size_t)oy * K * a.S + sc;
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) sp[(size_t)i * a.S] = cur[i];
+                }
+            } else if (code == OP_POPMUL) {
+                const double *sp = a.slots + (size_t)oy * K * a.S + sc;
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] *= sp[(size_t)i * a.S];
+            } else if (code == OP_SCALE) {
+                double m = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) m = fmax(m, cur[i]);
+                const int e = frexp_exp(m);
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] = ldexp(cur[i], -e);
+                esc += e;
+            }
+        }
+        double lh = 0.0;
+        if (a.root_mode == PLK_ROOT_NONE || a.root_mode == PLK_ROOT_UNIFORM) {
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (i < a.k) lh += cur[i];
+            if (a.root_mode == PLK_ROOT_UNIFORM) lh /= (double)a.k;
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; i++) lh = fma(rw[i], cur[i], lh);
+        }
+        const double term = prior[c] * lh;
+        if (term != 0.0) {
+            if (!have) { sum = term; Eexp = esc; have = true; }
+            else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
+            else sum += ldexp(term, esc - Eexp);
+        }
+    }
+    const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
+    if (valid && a.site_ll) a.site_ll[s] = ll;
+    if (a.partial) {
+        dd v = dd_make(0.0, 0.0);
+        if (valid) v = a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0);
+        dd r = dd_block_sum(v);
+        if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+/* tip[((c*(ntips+1) + t)*nchar + code)*K + i] = (P_e defs[code])[i] in double-double (exact for constant
+ * definition rows, src/util.c:276-283); slot ntips (edge -1) holds defs[code] itself; entries i >= k are 0
+ * for a product and 1... 0 for the padding of the definitions (the padded states never enter a product) */
+__global__ void k_build_tip_vec(int k, int K, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
+                                const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][K] */,
+                                double *__restrict__ tip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int e = tip_edge[t];
+    for (int idx = threadIdx.x; idx < nchar * K; idx += blockDim.x) {
+        const int code = idx / K, i = idx - code * K;
+        const double *d = defs + (size_t)code * K;
+        double out = 0.0;
+        if (i < k) {
+            if (e < 0) out = d[i];
+            else {
+                bool constant = true;
+                for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
+                if (constant) out = d[0];
+                else {
+                    const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                    dd acc = dd_make(0.0, 0.0);
+                    for (int j = 0; j < k; j++) acc = dd_add(acc, dd_mul_d(Pm[j], d[j]));
+                    out = acc.hi;
+                }
+            }
+        }
+        tip[(((size_t)c * (ntips + 1) + t) * nchar + code) * K + i] = out;
+    }
+}
+
+#endif

@@ -50,7 +50,13 @@ def test_site_ll_matches_oracle(eng, oracle, cfg, S, kind):
     eng.set_patterns_codes(codes, w.defs)
     got, (hi, lo) = eng.ll()
     kernel = eng.info(E.INFO_LL_KERNEL)
-    assert kernel == (1 if w.k == 4 else 3)       # fused assembly interpreter / fp64 MFMA kernel
+    assert kernel == (1 if w.k == 4 else 4 if w.k <= 32 else 3)   # assembly interpreter / register-resident vector / fp64 MFMA
+    if kernel == 4:
+        eng.set_option(E.OPT_MFMA, 2)                # the matrix-core kernel must agree as well
+        got3, _ = eng.ll()
+        assert eng.info(E.INFO_LL_KERNEL) == 3
+        assert rel_err(got3, want) <= TOL
+        eng.set_option(E.OPT_MFMA, 1)
     assert rel_err(got, want) <= TOL
     assert abs((hi + lo) - float(np.sum(want.astype(np.longdouble)))) <= TOL * abs(np.sum(want))
     # the generic (HBM-slot) traversal must agree too
