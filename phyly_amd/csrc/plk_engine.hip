@@ -1431,7 +1431,18 @@ static int prepare_stream(plk_engine *h, bool fused)
         HIPCHK(h, hipGetLastError());
     } else {
         if (!h->d_ops || h->stream_dirty) {
-            if ((rc = dev_upload(h, &h->d_ops, h->ops.data(), h->ops.size()))) return rc;
+            /* OP_MATVEC ops name the next OP_MATVEC (y, wrapping to the first): the vector kernel touches the
+             * cache lines of the next matrix while it multiplies with the current one */
+            std::vector<int2> gops(h->ops);
+            int first = -1, prev = -1;
+            for (int pc = 0; pc < nops; pc++)
+                if ((gops[pc].x & 0xff) == OP_MATVEC) {
+                    if (first < 0) first = pc;
+                    if (prev >= 0) gops[prev].y = pc;
+                    prev = pc;
+                }
+            if (prev >= 0) gops[prev].y = first;
+            if ((rc = dev_upload(h, &h->d_ops, gops.data(), gops.size()))) return rc;
             if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
         }
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;

@@ -20,7 +20,7 @@
 struct VecArgs {
     long S, Spad;
     int k, C, nops, ntips, nchar, root_mode;
-    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot */
+    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot; OP_MATVEC: y = pc of the next OP_MATVEC (wrapping) */
     const double *PS;         /* [C][nops][K*K]: PS[j*K + i] = P[i][j], zero padded */
     const double *tip;        /* [C][ntips+1][nchar][K]: P_e defs[code]; last slot = the definitions themselves */
     const uint8_t *codes;     /* [N][Spad] */
@@ -29,6 +29,48 @@ struct VecArgs {
     double *site_ll;
     dd *partial;
 };
+
+/* Touch every 64-byte line of the K x K matrix at p with scalar loads whose results are never used.  All waves
+ * of a CU walk the same matrix stream (C * nmat * K * K * 8 bytes, far larger than the 16 KB scalar cache), so
+ * without this every s_load of the product below waits for L2 (SQC_DCACHE_MISSES + _DUPLICATE = 60 % of the
+ * requests); with the lines requested one product ahead the operand loads hit.  The dummy destination is kept
+ * allocated until vec_touch_done(). */
+/* 16 lines starting at byte offset BASE; no wait */
+#define VEC_TOUCH16(D, P, BASE)                                                                                   \
+    asm volatile("s_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3\n\ts_load_dword %0, %1, %4\n\ts_load_dword %0, %1, %5\n\t" \
+                 "s_load_dword %0, %1, %6\n\ts_load_dword %0, %1, %7\n\ts_load_dword %0, %1, %8\n\ts_load_dword %0, %1, %9\n\t" \
+                 "s_load_dword %0, %1, %10\n\ts_load_dword %0, %1, %11\n\ts_load_dword %0, %1, %12\n\ts_load_dword %0, %1, %13\n\t" \
+                 "s_load_dword %0, %1, %14\n\ts_load_dword %0, %1, %15\n\ts_load_dword %0, %1, %16\n\ts_load_dword %0, %1, %17" \
+                 : "=&s"(D) : "s"(P), "n"((BASE) + 0x0), "n"((BASE) + 0x40), "n"((BASE) + 0x80), "n"((BASE) + 0xc0),  \
+                   "n"((BASE) + 0x100), "n"((BASE) + 0x140), "n"((BASE) + 0x180), "n"((BASE) + 0x1c0),              \
+                   "n"((BASE) + 0x200), "n"((BASE) + 0x240), "n"((BASE) + 0x280), "n"((BASE) + 0x2c0),              \
+                   "n"((BASE) + 0x300), "n"((BASE) + 0x340), "n"((BASE) + 0x380), "n"((BASE) + 0x3c0) : "memory")
+#define VEC_TOUCH2(D, P, BASE)                                                                                    \
+    asm volatile("s_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3" : "=&s"(D) : "s"(P), "n"((BASE) + 0x0), "n"((BASE) + 0x40) : "memory")
+
+struct VecTouch { unsigned d[9]; };
+
+template <int K>
+__device__ __forceinline__ VecTouch vec_touch(const PLK_AS4 double *p)
+{
+    VecTouch t = {};
+    constexpr int NL = K * K * 8 / 64;          /* 32 (K = 16), 50 (K = 20), 128 (K = 32) */
+    VEC_TOUCH16(t.d[0], p, 0x0);
+    VEC_TOUCH16(t.d[1], p, 0x400);
+    if constexpr (NL >= 48) VEC_TOUCH16(t.d[2], p, 0x800);
+    if constexpr (NL == 50) VEC_TOUCH2(t.d[3], p, 0xc00);
+    if constexpr (NL >= 64) VEC_TOUCH16(t.d[3], p, 0xc00);
+    if constexpr (NL >= 80) VEC_TOUCH16(t.d[4], p, 0x1000);
+    if constexpr (NL >= 96) VEC_TOUCH16(t.d[5], p, 0x1400);
+    if constexpr (NL >= 112) VEC_TOUCH16(t.d[6], p, 0x1800);
+    if constexpr (NL >= 128) VEC_TOUCH16(t.d[7], p, 0x1c00);
+    return t;
+}
+__device__ __forceinline__ void vec_touch_done(const VecTouch &t)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(t.d[0]), "s"(t.d[1]), "s"(t.d[2]), "s"(t.d[3]), "s"(t.d[4]), "s"(t.d[5]),
+                 "s"(t.d[6]), "s"(t.d[7]) : "memory");
+}
 
 template <int K>
 __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
@@ -44,6 +86,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
+    VecTouch td = {};
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -56,6 +99,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
                 const PLK_AS4 double *M = PSc + (size_t)pc * K * K;
+                vec_touch_done(td);      /* the lines requested after the previous product have arrived */
                 double acc[K];
 #pragma unroll
                 for (int i = 0; i < K; i++) acc[i] = M[i] * cur[0];
@@ -66,6 +110,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = acc[i];
+                /* request the lines of the next product's matrix (the next category's first one at the end);
+                 * the observation / stack ops in between hide the L2 latency */
+                const int nc = oy <= pc ? c + 1 : c;
+                td = vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oy) * K * K);
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
                 const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
                 const int ch = a.codes[(size_t)oy * a.Spad + sc];
@@ -114,6 +162,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
             else sum += ldexp(term, esc - Eexp);
         }
     }
+    vec_touch_done(td);
     const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
     if (valid && a.site_ll) a.site_ll[s] = ll;
     if (a.partial) {
