@@ -150,6 +150,11 @@ int plk_marginal(plk_engine *h, const int *node_mask,
 enum { PLK_COEF_PRIOR = 0, PLK_COEF_PRIOR_RATE_EDGE = 1, PLK_COEF_PRIOR_RATE = 2 };
 int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
                     const int *edge_mask, double *site_edge_out, double *edge_sums_out);
+/* nL direction matrices in one call (L_hi / L_lo: [nL][k][k]); site_out: NULL or [S][nL][E], sums_out: NULL or
+ * [nL][E][2].  The k = 4 kernels evaluate up to four directions per pass (shared down pass and forward vectors):
+ * em-update's two expectations, dwell per state, trans per state pair. */
+int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, const double *L_lo, int coef_mode,
+                          const int *edge_mask, double *site_out, double *sums_out);
 /* the scaled Frechet matrices coef_{c,e} * F_{c,e} themselves, [C][E][k][k] host (tests) */
 int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
                              double *F_out);

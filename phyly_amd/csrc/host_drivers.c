@@ -455,7 +455,7 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
     query q;
     int rc = -1;
     int *mask = NULL;
-    double **vals = NULL, **sums = NULL, *Lhi = NULL, *Llo = NULL;
+    double *vals_all = NULL, *sums_all = NULL, *Lall_hi = NULL, *Lall_lo = NULL, *Lhi = NULL, *Llo = NULL;
     long double *w_edge = NULL, *w_third = NULL, *Lacc = NULL;
     int npass = 0;
     query_init(&q);
@@ -477,9 +477,9 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
     if (edge_agg) host_reduction_weights(re, w_edge, &div_edge);
     if (third_agg) host_reduction_weights(rt, w_third, &div_third);
     npass = third_agg ? 1 : rt->selection_len;
-    vals = calloc((size_t)npass + 1, sizeof(double *));
-    sums = calloc((size_t)npass + 1, sizeof(double *));
-    if (!vals || !sums) goto done;
+    Lall_hi = calloc((size_t)npass * k * k + 1, sizeof(double));
+    Lall_lo = calloc((size_t)npass * k * k + 1, sizeof(double));
+    if (!Lall_hi || !Lall_lo) goto done;
     for (int t = 0; t < npass; t++) {
         /* direction matrix; for trans its entries are multiplied by the normalised rates
          * (src/arbplftrans.c:137-138, :196), hi/lo parts of Qn included */
@@ -502,20 +502,19 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
                 v /= div_third;
                 split_ld(v, &Lhi[i], &Llo[i]);
             }
-        if (site_agg) {
-            sums[t] = calloc((size_t)E * 2 + 2, sizeof(double));
-            if (!sums[t]) goto done;
-            if (q.U > 0 && re->selection_len > 0 && plk_edge_expect(q.eng, Lhi, Llo, coef, mask, NULL, sums[t])) {
-                fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
-            }
-        } else {
-            vals[t] = calloc((size_t)q.U * E + 1, sizeof(double));
-            if (!vals[t]) goto done;
-            if (q.U > 0 && re->selection_len > 0 && plk_edge_expect(q.eng, Lhi, Llo, coef, mask, vals[t], NULL)) {
-                fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
-            }
-        }
+        memcpy(Lall_hi + (size_t)t * k * k, Lhi, (size_t)k * k * sizeof(double));
+        memcpy(Lall_lo + (size_t)t * k * k, Llo, (size_t)k * k * sizeof(double));
     }
+    /* one engine call for all directions: the k = 4 kernels carry up to four of them per pass */
+    if (site_agg) sums_all = calloc((size_t)npass * E * 2 + 2, sizeof(double));
+    else vals_all = calloc((size_t)q.U * npass * E + 1, sizeof(double));
+    if (!sums_all && !vals_all) goto done;
+    if (q.U > 0 && re->selection_len > 0 && npass > 0 &&
+        plk_edge_expect_multi(q.eng, npass, Lall_hi, Lall_lo, coef, mask, vals_all, sums_all)) {
+        fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
+    }
+#define EXP_SUM(t, ce) (((long double)sums_all[((size_t)(t) * E + (ce)) * 2] + (long double)sums_all[((size_t)(t) * E + (ce)) * 2 + 1]) / q.div_site)
+#define EXP_VAL(t, u, ce) ((long double)vals_all[((size_t)(u) * npass + (t)) * E + (ce)])
     /* table header; the trans axis prints its two component indices (src/ndaccum.c:355-366, :401-409) */
     jbuf_puts(out, "{\"columns\": [");
     if (!site_agg) jbuf_puts(out, "\"site\", ");
@@ -535,14 +534,12 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
                     for (int ue = 0; ue < E; ue++) {
                         if (w_edge[ue] == 0) continue;
                         const int ce = q.m.edge_order[ue];
-                        long double x = site_agg ? ((long double)sums[t][2 * ce] + (long double)sums[t][2 * ce + 1]) / q.div_site
-                                                 : (long double)vals[t][(size_t)u * E + ce];
+                        long double x = site_agg ? EXP_SUM(t, ce) : EXP_VAL(t, u, ce);
                         v += x * w_edge[ue] / div_edge;
                     }
                 } else {
                     const int ce = q.m.edge_order[re->selection[ei]];
-                    v = site_agg ? ((long double)sums[t][2 * ce] + (long double)sums[t][2 * ce + 1]) / q.div_site
-                                 : (long double)vals[t][(size_t)u * E + ce];
+                    v = site_agg ? EXP_SUM(t, ce) : EXP_VAL(t, u, ce);
                 }
                 double d = clean(v);
                 if (check_finite(d, kind == 3 ? "a dwell expectation" : "a transition count expectation")) goto done;
@@ -564,9 +561,10 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
     jbuf_puts(out, "]}");
     rc = 0;
 done:
-    if (vals) for (int t = 0; t < npass; t++) free(vals[t]);
-    if (sums) for (int t = 0; t < npass; t++) free(sums[t]);
-    free(vals); free(sums); free(mask); free(w_edge); free(w_third); free(Lhi); free(Llo); free(Lacc);
+#undef EXP_SUM
+#undef EXP_VAL
+    free(vals_all); free(sums_all); free(Lall_hi); free(Lall_lo);
+    free(mask); free(w_edge); free(w_third); free(Lhi); free(Llo); free(Lacc);
     query_clear(&q);
     return rc;
 }
@@ -581,13 +579,13 @@ static int run_em_update(const jval *root, jbuf *out)
 {
     query q;
     int rc = -1;
-    double *Lhi = NULL, *Llo = NULL, *dw = NULL, *tr = NULL;
+    double *Lhi = NULL, *Llo = NULL, *dw = NULL, *tr = NULL, *both = NULL;
     query_init(&q);
     if (query_parse(&q, 5, root)) goto done;
     if (query_prepare(&q)) goto done;
     const int E = q.m.E, k = q.m.k;
-    Lhi = calloc((size_t)k * k + 1, sizeof(double));
-    Llo = calloc((size_t)k * k + 1, sizeof(double));
+    Lhi = calloc((size_t)k * k * 2 + 1, sizeof(double));
+    Llo = calloc((size_t)k * k * 2 + 1, sizeof(double));
     dw = calloc((size_t)E * 2 + 2, sizeof(double));
     tr = calloc((size_t)E * 2 + 2, sizeof(double));
     if (!Lhi || !Llo || !dw || !tr) goto done;
@@ -598,13 +596,17 @@ static int run_em_update(const jval *root, jbuf *out)
                 Lhi[i * k + j] = i == j ? -q.Qn[i * k + j] : 0.0;
                 Llo[i * k + j] = i == j ? -q.Qn_lo[i * k + j] : 0.0;
             }
-        if (plk_edge_expect(q.eng, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, dw)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
         for (int i = 0; i < k; i++)
             for (int j = 0; j < k; j++) {
-                Lhi[i * k + j] = i != j ? q.Qn[i * k + j] : 0.0;
-                Llo[i * k + j] = i != j ? q.Qn_lo[i * k + j] : 0.0;
+                Lhi[k * k + i * k + j] = i != j ? q.Qn[i * k + j] : 0.0;
+                Llo[k * k + i * k + j] = i != j ? q.Qn_lo[i * k + j] : 0.0;
             }
-        if (plk_edge_expect(q.eng, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, tr)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        /* both expectations in one call: [2][E][2] sums (dwell first) */
+        both = calloc((size_t)E * 4 + 4, sizeof(double));
+        if (!both) goto done;
+        if (plk_edge_expect_multi(q.eng, 2, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, both)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        memcpy(dw, both, (size_t)E * 2 * sizeof(double));
+        memcpy(tr, both + (size_t)E * 2, (size_t)E * 2 * sizeof(double));
     }
     jbuf_puts(out, "{\"columns\": [\"edge\", \"value\"], \"data\": [");
     for (int ue = 0; ue < E; ue++) {
@@ -620,7 +622,7 @@ static int run_em_update(const jval *root, jbuf *out)
     jbuf_puts(out, "]}");
     rc = 0;
 done:
-    free(Lhi); free(Llo); free(dw); free(tr);
+    free(Lhi); free(Llo); free(dw); free(tr); free(both);
     query_clear(&q);
     return rc;
 }

@@ -1823,10 +1823,11 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
 
 /* deriv / marginal for k = 4 with compact codes: interleaved-vector kernels (plk_updown4.h) */
 static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
-                       double *site_out, double *sums_out, const double *d_M, int dzero)
+                       double *site_out, double *sums_out, const double *d_M, int dzero, int nM)
 {
     int rc;
     const int N = h->N, E = h->E, C = h->C;
+    const int ER = nM * E;                 /* rows of the edge-form output: [form][edge] */
     const long S = h->S;
     if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
     const int ntips = (int)h->tip_edge.size();
@@ -1900,18 +1901,19 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         (rc = dev_upload(h, &d_ops2, ops2.data(), ops2.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
         (rc = dev_upload(h, &d_obs2, h->obs_nodes.data(), h->obs_nodes.size())) ||
         (rc = dev_upload(h, &d_inl, node_inline.data(), (size_t)N)) ||
-        (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab))) { cleanup(); return rc; }
+        (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab * nM))) { cleanup(); return rc; }
     if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
     { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
                        E, ntips + 1, h->nchar, d_te, h->d_Pdd, h->d_defs, d_tip4);
-    hipLaunchKernelGGL(k_build_dtip4, dim3(ntips + 1, C), dim3(64), 0, h->stream,
-                       E, ntips, h->nchar, d_te, d_M, h->d_defs, d_dtip4, dzero);
+    for (int m = 0; m < nM; m++)
+        hipLaunchKernelGGL(k_build_dtip4, dim3(ntips + 1, C), dim3(64), 0, h->stream,
+                           E, ntips, h->nchar, d_te, d_M + (size_t)m * C * E * 16, h->d_defs, d_dtip4 + (size_t)m * ntab, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? ER : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -1922,7 +1924,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     if (chunk < S) chunk = std::max<long>(UD4_BLOCK, chunk / UD4_BLOCK * UD4_BLOCK);
     if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
 
-    std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * 4 : 0, 0.0L);
+    std::vector<long double> dsum(deriv ? ER : 0, 0.0L), msum(marg ? (size_t)N * 4 : 0, 0.0L);
     std::vector<double> stage;
     for (long s0 = 0; s0 < S; s0 += chunk) {
         const long n = std::min(chunk, S - s0);
@@ -1932,7 +1934,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.dzero = dzero;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.edge_tip = d_et; a.edge_int = d_ei; a.node_int = d_ni; a.node_scale = d_ns; a.node_inline = d_inl;
-        a.P = h->d_P; a.dP = d_M; a.tip = d_tip4; a.dtip = d_dtip4;
+        a.P = h->d_P; a.dP = d_M; a.tip = d_tip4; a.dtip = d_dtip4; a.nM = nM;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = d_emask; a.node_mask = d_nmask;
         double *p = h->d_work;
         a.LN = p; p += (size_t)nin * C * 4 * n;
@@ -1941,9 +1943,9 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.CW = p; p += (size_t)C * n;
         a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
-        a.DV = p; if (deriv) p += (size_t)E * n;
+        a.DV = p; if (deriv) p += (size_t)ER * n;
         a.MV = p; if (marg) p += (size_t)N * 4 * n;
-        if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
         const size_t lds_codes = (size_t)nobs2 * UD4_BLOCK;
@@ -1953,16 +1955,19 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         else if (fused_ok && h->slots_needed <= 16) hipLaunchKernelGGL(k_down_fused4<16>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
         else hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (deriv && nM == 2) hipLaunchKernelGGL((k_up4<true, false, 2>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (deriv && nM == 3) hipLaunchKernelGGL((k_up4<true, false, 3>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (deriv && nM == 4) hipLaunchKernelGGL((k_up4<true, false, 4>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv) hipLaunchKernelGGL((k_up4<true, false>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else hipLaunchKernelGGL((k_up4<false, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;
-            if (deriv && E > 0 && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
+            if (deriv && E > 0 && (rc = wsum_rows(h, ER, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
             if (marg && (rc = wsum_rows(h, N * 4, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
         if (site_out) {
-            const size_t rows = deriv ? (size_t)E : (size_t)N * 4;
+            const size_t rows = deriv ? (size_t)ER : (size_t)N * 4;
             stage.resize(rows * (size_t)n);
             hipError_t e = hipSuccess;
             if (rows) e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1994,7 +1999,7 @@ static bool use_updown4(const plk_engine *h)
 /* d_M: the per-(category, edge) matrices of the edge bilinear form fe^T M L_b: dP for the derivative
  * (dzero = 1: rows sum to zero), scaled Frechet matrices for dwell / trans / em-update (dzero = 0) */
 static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
-                      double *site_out, double *sums_out, const double *d_M_in = nullptr, int dzero = 1)
+                      double *site_out, double *sums_out, const double *d_M_in = nullptr, int dzero = 1, int nM = 1)
 {
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_deriv/plk_marginal: tree, model and patterns must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -2002,7 +2007,8 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     const double *d_M = d_M_in ? d_M_in : h->d_dP;
     if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
-    if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
+    if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero, nM);
+    if (nM != 1) { h->err = "internal: several edge forms per pass need the k = 4 kernels"; return PLK_E_ARG; }
     const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
     const long S = h->S;
     /* padded edge-indexed streams */
@@ -2118,24 +2124,24 @@ extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_
     return run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out);
 }
 
-/* Conditional edge expectations (dwell / trans / em-update numerators): replaces
- * src/evaluate_site_frechet.c:5-42 + the Frechet matrix set-up of src/arbplfdwell.c:117-204,
- * src/arbplftrans.c:116-224, src/arbplfem.c:100-158. */
-extern "C" int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
-                               const int *edge_mask, double *site_edge_out, double *edge_sums_out)
+/* Several direction matrices at once: the k = 4 kernels carry up to four edge forms per pass (one down pass, one
+ * up pass, shared forward vectors); other state counts run one pass per direction.
+ * site_out: NULL or [S][nL][E]; sums_out: NULL or [nL][E][2]. */
+extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, const double *L_lo, int coef_mode,
+                                     const int *edge_mask, double *site_out, double *sums_out)
 {
     if (!h) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_edge_expect: tree, model and patterns must be set"; return PLK_E_ARG; }
-    if (!L_hi || coef_mode < PLK_COEF_PRIOR || coef_mode > PLK_COEF_PRIOR_RATE) { h->err = "plk_edge_expect: bad direction matrix or coefficient mode"; return PLK_E_ARG; }
+    if (!L_hi || nL < 1 || coef_mode < PLK_COEF_PRIOR || coef_mode > PLK_COEF_PRIOR_RATE) { h->err = "plk_edge_expect: bad direction matrix or coefficient mode"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     const int k = h->k, C = h->C, E = h->E;
+    const long S = h->S;
     if (E == 0) return PLK_OK;
     const size_t kk = (size_t)k * k, n2 = 4 * kk;
-    std::vector<double> L(2 * kk, 0.0);
-    std::copy(L_hi, L_hi + kk, L.begin());
-    if (L_lo) std::copy(L_lo, L_lo + kk, L.begin() + kk);
+    /* how many directions one pass of the kernels can carry */
+    const int per_pass = use_updown4(h) && !use_mfma(h) ? 4 : 1;
     double *d_L = nullptr, *d_F = nullptr;
     int *d_mask = nullptr;
     dd *d_scr = nullptr;
@@ -2145,19 +2151,51 @@ extern "C" int plk_edge_expect(plk_engine *h, const double *L_hi, const double *
         if (d_mask) (void)hipFree(d_mask);
         if (d_scr) (void)hipFree(d_scr);
     };
-    if ((rc = dev_upload(h, &d_L, L.data(), L.size())) || (rc = dev_alloc(h, &d_F, (size_t)C * E * kk))) { cleanup(); return rc; }
+    if ((rc = dev_alloc(h, &d_L, 2 * kk)) || (rc = dev_alloc(h, &d_F, (size_t)per_pass * C * E * kk))) { cleanup(); return rc; }
     if (edge_mask && (rc = dev_upload(h, &d_mask, edge_mask, (size_t)E))) { cleanup(); return rc; }
     const size_t lds_bytes = 4 * n2 * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
     if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * 4 * n2))) { cleanup(); return rc; }
     const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
-    hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
-                       k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
-                       d_scr, use_lds, d_L, coef_mode, d_mask, d_F);
-    if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_edge_expect: Frechet kernel launch failed"; return PLK_E_DEVICE; }
-    rc = run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out, d_F, 0);
+    std::vector<double> L(2 * kk), tmp_site, tmp_sums;
+    for (int m0 = 0; m0 < nL; m0 += per_pass) {
+        const int nm = std::min(per_pass, nL - m0);
+        for (int m = 0; m < nm; m++) {
+            std::copy(L_hi + (size_t)(m0 + m) * kk, L_hi + (size_t)(m0 + m + 1) * kk, L.begin());
+            if (L_lo) std::copy(L_lo + (size_t)(m0 + m) * kk, L_lo + (size_t)(m0 + m + 1) * kk, L.begin() + kk);
+            else std::fill(L.begin() + kk, L.end(), 0.0);
+            hipError_t e = hipMemcpyAsync(d_L, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+                                   k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
+                                   d_scr, use_lds, d_L, coef_mode, d_mask, d_F + (size_t)m * C * E * kk);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      /* L is reused for the next direction */
+            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_edge_expect: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+        }
+        /* outputs of this pass: [S][nm*E] and [nm*E][2]; scattered into [S][nL*E] / [nL*E][2] */
+        double *so = nullptr, *su = nullptr;
+        if (site_out) { if (nm == nL) so = site_out; else { tmp_site.assign((size_t)S * nm * E, 0.0); so = tmp_site.data(); } }
+        if (sums_out) su = sums_out + (size_t)m0 * E * 2;
+        rc = run_updown(h, true, false, edge_mask, nullptr, so, su, d_F, 0, nm);
+        if (rc) { cleanup(); return rc; }
+        if (site_out && nm != nL)
+            for (long s = 0; s < S; s++)
+                for (int r = 0; r < nm * E; r++)
+                    site_out[((size_t)s * nL + m0) * E + r] = tmp_site[(size_t)s * nm * E + r];
+    }
     cleanup();
-    return rc;
+    return PLK_OK;
+}
+
+/* Conditional edge expectations (dwell / trans / em-update numerators): replaces
+ * src/evaluate_site_frechet.c:5-42 + the Frechet matrix set-up of src/arbplfdwell.c:117-204,
+ * src/arbplftrans.c:116-224, src/arbplfem.c:100-158. */
+extern "C" int plk_edge_expect(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode,
+                               const int *edge_mask, double *site_edge_out, double *edge_sums_out)
+{
+    return plk_edge_expect_multi(h, 1, L_hi, L_lo, coef_mode, edge_mask, site_edge_out, edge_sums_out);
 }
 
 extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode, double *F_out)
@@ -2257,8 +2295,13 @@ extern "C" int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, doubl
                 else { Lt[q] = h->Qn[q]; Lt[kk + q] = h->Qn[kk + q]; }
             }
         for (; it < max_iter && !free_e.empty(); ) {
-            if ((rc = plk_edge_expect(h, Ld.data(), Ld.data() + kk, PLK_COEF_PRIOR_RATE, mask.data(), nullptr, dw.data()))) return rc;
-            if ((rc = plk_edge_expect(h, Lt.data(), Lt.data() + kk, PLK_COEF_PRIOR_RATE, mask.data(), nullptr, tr.data()))) return rc;
+            /* both expectations in one pass where the kernels allow it */
+            std::vector<double> Lh(2 * kk), Ll(2 * kk), both((size_t)4 * E + 4);
+            std::copy(Ld.begin(), Ld.begin() + kk, Lh.begin()); std::copy(Lt.begin(), Lt.begin() + kk, Lh.begin() + kk);
+            std::copy(Ld.begin() + kk, Ld.end(), Ll.begin()); std::copy(Lt.begin() + kk, Lt.end(), Ll.begin() + kk);
+            if ((rc = plk_edge_expect_multi(h, 2, Lh.data(), Ll.data(), PLK_COEF_PRIOR_RATE, mask.data(), nullptr, both.data()))) return rc;
+            std::copy(both.begin(), both.begin() + 2 * E, dw.begin());
+            std::copy(both.begin() + 2 * E, both.begin() + 4 * E, tr.begin());
             for (int e : free_e) {
                 const long double t = (long double)tr[2 * e] + (long double)tr[2 * e + 1];
                 const long double d = (long double)dw[2 * e] + (long double)dw[2 * e + 1];

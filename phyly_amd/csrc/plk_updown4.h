@@ -30,8 +30,9 @@ struct Up4Args {
     int dzero;                     /* 1: edge-form matrices have zero row sums (dP) */
     const int *indptr, *indices, *preorder;
     const int *node_has_data, *edge_tip, *edge_int, *node_int;
-    const double *P, *dP;          /* [C][E][4][4] row-major */
-    const double *tip, *dtip;      /* [C][ntips+1][nchar][4]; slot ntips of tip = raw definitions */
+    const double *P, *dP;          /* [C][E][4][4] row-major; dP: [nM] such sets (the edge-form matrices) */
+    const double *tip, *dtip;      /* [C][ntips+1][nchar][4]; slot ntips of tip = raw definitions; dtip: [nM] sets */
+    int nM;                        /* edge forms evaluated in this pass (1 for deriv; DV is [nM][E][n]) */
     const uint8_t *codes;
     const double *cat_prior, *root_w;
     const int *edge_mask, *node_mask;
@@ -309,9 +310,10 @@ __device__ static inline Ud4Pre ud4_pre(const Up4Args &a, int b, long sg)
 }
 
 /* one category of such a node: fb is its forward vector */
-__device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double *tipc, const double *dtipc,
+template <int NM>
+__device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double *tipc, const double *dtipc, size_t dstride,
                                            const PLK_AS4 double *Pm, double pc, size_t n, long slc, const v4 &fb,
-                                           const Ud4Pre &q, double &pd0, double &pd1, v4 &pm0, v4 &pm1)
+                                           const Ud4Pre &q, double (&pd0)[NM], double (&pd1)[NM], v4 &pm0, v4 &pm1)
 {
     v4 g = fb;
     if (q.hd) g = mul4(g, ld4(tipc + ((size_t)a.ntips * a.nchar + q.chn) * 4));
@@ -325,12 +327,18 @@ __device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double
         fe1 = mul4(g, ld4(tipc + ((size_t)q.t0 * a.nchar + q.cd0) * 4));
     }
     if (q.wd0) {
-        const v4 y = ld4(dtipc + ((size_t)q.t0 * a.nchar + q.cd0) * 4);
-        pd0 = fma(pc, fma(fe0.d, y.d, fma(fe0.c, y.c, fma(fe0.b, y.b, fe0.a * y.a))), pd0);
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const v4 y = ld4(dtipc + m * dstride + ((size_t)q.t0 * a.nchar + q.cd0) * 4);
+            pd0[m] = fma(pc, fma(fe0.d, y.d, fma(fe0.c, y.c, fma(fe0.b, y.b, fe0.a * y.a))), pd0[m]);
+        }
     }
     if (q.wd1) {
-        const v4 y = ld4(dtipc + ((size_t)q.t1 * a.nchar + q.cd1) * 4);
-        pd1 = fma(pc, fma(fe1.d, y.d, fma(fe1.c, y.c, fma(fe1.b, y.b, fe1.a * y.a))), pd1);
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const v4 y = ld4(dtipc + m * dstride + ((size_t)q.t1 * a.nchar + q.cd1) * 4);
+            pd1[m] = fma(pc, fma(fe1.d, y.d, fma(fe1.c, y.c, fma(fe1.b, y.b, fe1.a * y.a))), pd1[m]);
+        }
     }
     if (q.wm0) {
         const v4 f = mtv4(Pm + ((size_t)c * a.E + q.idx0) * 16, fe0);
@@ -346,11 +354,15 @@ __device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double
     }
 }
 
+template <int NM>
 __device__ static inline void ud4_pre_write(const Up4Args &a, size_t n, long sl, double inv, const Ud4Pre &q,
-                                            double pd0, double pd1, const v4 &pm0, const v4 &pm1)
+                                            const double (&pd0)[NM], const double (&pd1)[NM], const v4 &pm0, const v4 &pm1)
 {
-    if (q.wd0) a.DV[(size_t)q.idx0 * n + sl] = pd0 * inv;
-    if (q.wd1) a.DV[(size_t)q.idx1 * n + sl] = pd1 * inv;
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        if (q.wd0) a.DV[((size_t)m * a.E + q.idx0) * n + sl] = pd0[m] * inv;
+        if (q.wd1) a.DV[((size_t)m * a.E + q.idx1) * n + sl] = pd1[m] * inv;
+    }
     if (q.wm0) {
         double *mv = a.MV + (size_t)q.b0 * 4 * n + sl;
         mv[0] = pm0.a * inv; mv[n] = pm0.b * inv; mv[2 * n] = pm0.c * inv; mv[3 * n] = pm0.d * inv;
@@ -361,7 +373,7 @@ __device__ static inline void ud4_pre_write(const Up4Args &a, size_t n, long sl,
     }
 }
 
-template <bool DERIV, bool MARG>
+template <bool DERIV, bool MARG, int NM = 1>
 __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
 {
     const long sl = (long)blockIdx.x * UD4_BLOCK + threadIdx.x;
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
     const PLK_AS4 double *Pm = as_uniform(a.P), *Mm = as_uniform(a.dP);
     const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
+    const size_t mstride = (size_t)a.C * a.E * 16, dstride = (size_t)a.C * tabc;   /* between edge-form sets */
     const double inv = 1.0 / a.LH[slc];
     const int root = pre[0];
     const v4 w = v4{rw[0], rw[1], rw[2], rw[3]};
@@ -417,14 +430,18 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
             c1.want_m = MARG && deg == 2 && (!a.node_mask || as_uniform(a.node_mask)[c1.b]);
             c0.want_f = c0.t < 0 || c0.want_m;
             c1.want_f = deg == 2 && (c1.t < 0 || c1.want_m);
-            double d0 = 0.0, d1 = 0.0;
+            double d0[NM], d1[NM];
+#pragma unroll
+            for (int m = 0; m < NM; m++) d0[m] = d1[m] = 0.0;
             v4 m0 = zero, m1 = zero;
             const bool in0 = c0.t < 0 && as_uniform(a.node_inline)[c0.b];
             const bool in1 = deg == 2 && c1.t < 0 && as_uniform(a.node_inline)[c1.b];
             Ud4Pre q0 = {}, q1 = {};
             if (in0) q0 = ud4_pre<DERIV, MARG>(a, c0.b, sg);
             if (in1) q1 = ud4_pre<DERIV, MARG>(a, c1.b, sg);
-            double p00 = 0.0, p01 = 0.0, p10 = 0.0, p11 = 0.0;
+            double p00[NM], p01[NM], p10[NM], p11[NM];
+#pragma unroll
+            for (int m = 0; m < NM; m++) p00[m] = p01[m] = p10[m] = p11[m] = 0.0;
             v4 r00 = zero, r01 = zero, r10 = zero, r11 = zero;
             for (int c = 0; c < a.C; c++) {
                 const double *tipc = a.tip + (size_t)c * tabc;
@@ -446,17 +463,19 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                 }
 #define UD4_EDGE(CH, FE, X, DS, MS, INL, Q, PA, PB, RA, RB)                                                 \
                 if (CH.want_d) {                                                                            \
-                    v4 y;                                                                                   \
-                    if (CH.t >= 0) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)CH.t * a.nchar + CH.code) * 4); \
-                    else {                                                                                  \
-                        y = mv4(Mm + ((size_t)c * a.E + CH.idx) * 16, X);                                   \
-                        if (a.dzero && const4(X)) y = zero;      /* rows of dP sum to zero (src/util.c:338-345) */ \
+                    _Pragma("unroll") for (int m = 0; m < NM; m++) {                                        \
+                        v4 y;                                                                               \
+                        if (CH.t >= 0) y = ld4(dtipc + m * dstride + ((size_t)CH.t * a.nchar + CH.code) * 4); \
+                        else {                                                                              \
+                            y = mv4(Mm + m * mstride + ((size_t)c * a.E + CH.idx) * 16, X);                 \
+                            if (a.dzero && const4(X)) y = zero;  /* rows of dP sum to zero (src/util.c:338-345) */ \
+                        }                                                                                   \
+                        DS[m] = fma(pc, fma(FE.d, y.d, fma(FE.c, y.c, fma(FE.b, y.b, FE.a * y.a))), DS[m]); \
                     }                                                                                       \
-                    DS = fma(pc, fma(FE.d, y.d, fma(FE.c, y.c, fma(FE.b, y.b, FE.a * y.a))), DS);           \
                 }                                                                                           \
                 if (CH.want_f) {                                                                            \
                     const v4 fb = mtv4(Pm + ((size_t)c * a.E + CH.idx) * 16, FE);                           \
-                    if (INL) ud4_pre_step(a, c, tipc, dtipc, Pm, pc, n, slc, fb, Q, PA, PB, RA, RB);        \
+                    if (INL) ud4_pre_step<NM>(a, c, tipc, dtipc, dstride, Pm, pc, n, slc, fb, Q, PA, PB, RA, RB); \
                     else if (CH.t < 0 && valid) st4(a.FN + (((size_t)nint[CH.b] * a.C + c) * n + slc) * 4, fb);  \
                     if (CH.want_m) {                                                                        \
                         const v4 lb = CH.t >= 0 ? ld4(tipc + ((size_t)a.ntips * a.nchar + CH.code) * 4) : X; \
@@ -469,10 +488,13 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
 #undef UD4_EDGE
             }
             if (valid) {
-                if (in0) ud4_pre_write(a, n, sl, inv, q0, p00, p01, r00, r01);
-                if (in1) ud4_pre_write(a, n, sl, inv, q1, p10, p11, r10, r11);
-                if (c0.want_d) a.DV[(size_t)c0.idx * n + sl] = d0 * inv;
-                if (c1.want_d) a.DV[(size_t)c1.idx * n + sl] = d1 * inv;
+                if (in0) ud4_pre_write<NM>(a, n, sl, inv, q0, p00, p01, r00, r01);
+                if (in1) ud4_pre_write<NM>(a, n, sl, inv, q1, p10, p11, r10, r11);
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    if (c0.want_d) a.DV[((size_t)m * a.E + c0.idx) * n + sl] = d0[m] * inv;
+                    if (c1.want_d) a.DV[((size_t)m * a.E + c1.idx) * n + sl] = d1[m] * inv;
+                }
                 if (c0.want_m) {
                     double *mv = a.MV + (size_t)c0.b * 4 * n + sl;
                     mv[0] = m0.a * inv; mv[n] = m0.b * inv; mv[2 * n] = m0.c * inv; mv[3 * n] = m0.d * inv;
@@ -492,10 +514,13 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
             ch.want_m = MARG && (!a.node_mask || as_uniform(a.node_mask)[ch.b]);
             ch.want_f = ch.t < 0 || ch.want_m;
             if (!ch.want_d && !ch.want_f) continue;
-            double dsum = 0.0;
+            double dsum[NM];
+#pragma unroll
+            for (int m = 0; m < NM; m++) dsum[m] = 0.0;
             v4 macc = zero;
             for (int c = 0; c < a.C; c++) {
                 const double *tipc = a.tip + (size_t)c * tabc;
+                const double *dtipc = a.dtip + (size_t)c * tabc;
                 v4 fe = ld4(fn_nd + ((size_t)c * n + slc) * 4);
                 if (hd) fe = mul4(fe, ld4(tipc + ((size_t)a.ntips * a.nchar + chn) * 4));
                 if (slot >= 0) {
@@ -515,13 +540,16 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                 v4 x = zero;
                 if (ch.t < 0) x = ld4(a.LN + (((size_t)nint[ch.b] * a.C + c) * n + slc) * 4);
                 if (ch.want_d) {
-                    v4 y;
-                    if (ch.t >= 0) y = ld4(a.dtip + (size_t)c * tabc + ((size_t)ch.t * a.nchar + ch.code) * 4);
-                    else {
-                        y = mv4(Mm + ((size_t)c * a.E + idx) * 16, x);
-                        if (a.dzero && const4(x)) y = zero;
+#pragma unroll
+                    for (int m = 0; m < NM; m++) {
+                        v4 y;
+                        if (ch.t >= 0) y = ld4(dtipc + m * dstride + ((size_t)ch.t * a.nchar + ch.code) * 4);
+                        else {
+                            y = mv4(Mm + m * mstride + ((size_t)c * a.E + idx) * 16, x);
+                            if (a.dzero && const4(x)) y = zero;
+                        }
+                        dsum[m] = fma(pc, fma(fe.d, y.d, fma(fe.c, y.c, fma(fe.b, y.b, fe.a * y.a))), dsum[m]);
                     }
-                    dsum = fma(pc, fma(fe.d, y.d, fma(fe.c, y.c, fma(fe.b, y.b, fe.a * y.a))), dsum);
                 }
                 if (ch.want_f) {
                     const v4 fb = mtv4(Pm + ((size_t)c * a.E + idx) * 16, fe);
@@ -533,7 +561,10 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                     }
                 }
             }
-            if (ch.want_d && valid) a.DV[(size_t)idx * n + sl] = dsum * inv;
+            if (ch.want_d && valid) {
+#pragma unroll
+                for (int m = 0; m < NM; m++) a.DV[((size_t)m * a.E + idx) * n + sl] = dsum[m] * inv;
+            }
             if (ch.want_m && valid) {
                 double *mv = a.MV + (size_t)ch.b * 4 * n + sl;
                 mv[0] = macc.a * inv; mv[n] = macc.b * inv; mv[2 * n] = macc.c * inv; mv[3 * n] = macc.d * inv;

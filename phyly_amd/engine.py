@@ -56,6 +56,7 @@ def load_library():
     lib.plk_deriv.argtypes = [vp, vp, vp, vp]
     lib.plk_marginal.argtypes = [vp, vp, vp, vp]
     lib.plk_edge_expect.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+    lib.plk_edge_expect_multi.argtypes = [vp, ci, vp, vp, ci, vp, vp, vp]
     lib.plk_get_frechet_matrices.argtypes = [vp, vp, vp, ci, vp]
     lib.plk_fit_edge_rates.argtypes = [vp, ci, ci, ctypes.c_double, vp, vp, vp, ctypes.POINTER(ci), ctypes.POINTER(cl)]
     lib.plk_hess.argtypes = [vp, vp]
@@ -192,6 +193,18 @@ class Engine:
         out = np.zeros((self.S, self.E)) if per_site else None
         sums = np.zeros((self.E, 2)) if want_sums else None
         self._check(self._lib.plk_edge_expect(self._h, _ptr(L), _ptr(L_lo), int(coef_mode), _ptr(mask), _ptr(out), _ptr(sums)))
+        return out, sums
+
+    def edge_expect_multi(self, Ls, coef_mode, Ls_lo=None, edge_mask=None, per_site=True, want_sums=True):
+        """several direction matrices in one call: Ls [nL][k][k] -> ([S][nL][E], [nL][E][2])"""
+        mask = _i32(edge_mask) if edge_mask is not None else None
+        Ls = _f64(Ls)
+        nL = Ls.shape[0]
+        Ls_lo = _f64(Ls_lo) if Ls_lo is not None else None
+        out = np.zeros((self.S, nL, self.E)) if per_site else None
+        sums = np.zeros((nL, self.E, 2)) if want_sums else None
+        self._check(self._lib.plk_edge_expect_multi(self._h, int(nL), _ptr(Ls), _ptr(Ls_lo), int(coef_mode), _ptr(mask),
+                                                    _ptr(out), _ptr(sums)))
         return out, sums
 
     def frechet_matrices(self, L, coef_mode, L_lo=None):

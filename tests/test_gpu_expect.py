@@ -135,6 +135,28 @@ def test_edge_expect_matches_oracle(eng, oracle, cfg, S, nreq):
         assert np.max(np.abs(tot[sel] - ref[sel])) <= 1e-12 * np.max(np.abs(ref[sel])), name
 
 
+@pytest.mark.parametrize("cfg,S,nL", [(3, 300, 2), (3, 257, 5), (2, 64, 4), (4, 16, 3)])
+def test_edge_expect_multi_equals_single_calls(eng, cfg, S, nL):
+    """several directions per pass (k = 4: up to four share one down / up pass; more are split; other k: one pass
+    each) must give exactly what the single-direction entry point gives"""
+    from phyly_amd import synth, engine as E
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    codes = w.random_codes(S, seed=cfg)
+    eng.set_patterns_codes(codes, w.defs)
+    wts = np.linspace(0.5, 1.5, S)
+    eng.set_site_weights(wts)
+    rng = np.random.default_rng(5 + nL)
+    Ls = rng.uniform(-1, 1, (nL, w.k, w.k))
+    mask = (rng.random(w.E) < 0.7).astype(np.int32)
+    got, gsum = eng.edge_expect_multi(Ls, E.COEF_PRIOR_RATE_EDGE, edge_mask=mask)
+    for m in range(nL):
+        one, osum = eng.edge_expect(Ls[m], E.COEF_PRIOR_RATE_EDGE, edge_mask=mask)
+        assert np.array_equal(got[:, m, :], one)
+        assert np.array_equal(gsum[m], osum)
+    eng.set_site_weights(None)
+
+
 @pytest.mark.parametrize("cfg,nreq", [(3, 198), (4, 6), (5, 2)])
 def test_frechet_matrices_match_oracle(eng, oracle, cfg, nreq):
     """the device double-double block exponential against the binary128 one, entry by entry"""
