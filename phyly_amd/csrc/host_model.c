@@ -199,6 +199,40 @@ static int parse_character_data(host_model *m, const jval *cd, const jval *defs)
     return 0;
 }
 
+/*
+ * Binary side channel for alignments that JSON cannot carry (an extension, the reference has no
+ * counterpart): "character_data_file" names a raw file of S * N bytes, the same [site][node] character indices that
+ * "character_data" would list, used together with "character_definitions" (at most 256 of them).
+ */
+static int parse_character_data_file(host_model *m, const jval *path, const jval *defs)
+{
+    const char *name = "character_data_file";
+    if (!j_is_string(path)) FAILF("%s: expected the path of a raw byte file\n", name);
+    if (!j_is_array(defs)) FAILF("%s: expected 'character_definitions' to be an array\n", name);
+    const int N = m->N, k = m->k, nchar = (int)j_len(defs);
+    if (nchar < 1 || nchar > 256) FAILF("%s: between 1 and 256 character definitions are required\n", name);
+    m->nchar = nchar;
+    m->defs = malloc(((size_t)nchar * k + 1) * sizeof(double));
+    if (!m->defs) return -1;
+    for (int c = 0; c < nchar; c++)
+        if (nonneg_array(m->defs + (size_t)c * k, k, j_at(defs, c), name)) return -1;
+    FILE *f = fopen(path->u.s, "rb");
+    if (!f) FAILF("%s: cannot open '%s'\n", name, path->u.s);
+    if (fseek(f, 0, SEEK_END)) { fclose(f); FAILF("%s: cannot seek in '%s'\n", name, path->u.s); }
+    const long bytes = ftell(f);
+    rewind(f);
+    if (bytes < 0 || bytes % N) { fclose(f); FAILF("%s: the size of '%s' (%ld bytes) is not a multiple of the node count (%d)\n", name, path->u.s, bytes, N); }
+    m->S = bytes / N;
+    m->codes8 = malloc((size_t)bytes + 1);
+    if (!m->codes8) { fclose(f); return -1; }
+    const size_t got = fread(m->codes8, 1, (size_t)bytes, f);
+    fclose(f);
+    if (got != (size_t)bytes) FAILF("%s: short read from '%s'\n", name, path->u.s);
+    for (long i = 0; i < bytes; i++)
+        if (m->codes8[i] >= nchar) FAILF("%s: character indices must each be less than the character count (%d)\n", name, nchar);
+    return 0;
+}
+
 static int parse_rate_divisor(host_model *m, const jval *rd)
 {
     const char *msg = "_validate_rate_divisor: the optional rate_divisor argument must be either a positive number "
@@ -286,15 +320,17 @@ int host_model_parse(host_model *m, const jval *root)
 {
     static const char *const req[] = {"edges", "edge_rate_coefficients", "rate_matrix", NULL};
     static const char *const all[] = {"edges", "edge_rate_coefficients", "rate_matrix", "probability_array",
-        "character_definitions", "character_data", "rate_divisor", "root_prior", "rate_mixture",
+        "character_definitions", "character_data", "character_data_file", "rate_divisor", "root_prior", "rate_mixture",
         "gamma_rate_mixture", "normalized_median_gamma_rate_mixture", NULL};
     if (host_check_keys(root, req, all, "model_and_data")) return -1;
     const jval *pa = j_get(root, "probability_array"), *cdefs = j_get(root, "character_definitions");
     const jval *cdata = j_get(root, "character_data"), *rmix = j_get(root, "rate_mixture");
+    const jval *cfile = j_get(root, "character_data_file");
     const jval *gmix = j_get(root, "gamma_rate_mixture"), *gmed = j_get(root, "normalized_median_gamma_rate_mixture");
     if (exists(rmix) + exists(gmix) + exists(gmed) > 1) FAILF("error: conflicting rate mixture options\n");
     if (exists(pa) && exists(cdata)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_data' have both been specified\n");
     if (exists(pa) && exists(cdefs)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_definitions' have both been specified\n");
+    if (exists(cfile) && (exists(pa) || exists(cdata))) FAILF("error: 'character_data_file' excludes 'probability_array' and 'character_data'\n");
 
     if (parse_edges(m, j_get(root, "edges"))) return -1;
     m->edge_rates_user = malloc((size_t)(m->E + 1) * sizeof(double));
@@ -305,6 +341,7 @@ int host_model_parse(host_model *m, const jval *root)
     if (parse_rate_matrix(m, j_get(root, "rate_matrix"))) return -1;
     if (exists(pa)) { if (parse_probability_array(m, pa)) return -1; }
     else if (exists(cdata)) { if (parse_character_data(m, cdata, cdefs)) return -1; }
+    else if (exists(cfile)) { if (parse_character_data_file(m, cfile, cdefs)) return -1; }
     else FAILF("error: either 'probability_array' or 'character_data' must be specified\n");
     if (parse_rate_divisor(m, j_get(root, "rate_divisor"))) return -1;
     if (parse_root_prior(m, j_get(root, "root_prior"))) return -1;

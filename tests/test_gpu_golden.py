@@ -105,3 +105,27 @@ def test_cli_matches_golden():
     p = subprocess.run([os.path.abspath(os.path.join(csrc, "arbplf-ll"))], input=b'{"model_and_data": {}}',
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and p.stdout == b"" and p.stderr
+
+
+def test_character_data_file_equals_inline(tmp_path):
+    """the binary side channel gives the same tables as the same alignment written inline"""
+    import arbplf
+    rng = np.random.default_rng(12)
+    N, k, S = 9, 4, 3000
+    edges = [[8, 0], [8, 7], [7, 1], [7, 6], [6, 2], [6, 5], [5, 3], [5, 4]]
+    codes = rng.integers(0, k + 1, (S, N)).astype(np.uint8)
+    codes[:, 5:] = k                                     # internal nodes unobserved
+    md = {"edges": edges, "edge_rate_coefficients": [0.1, 0.2, 0.05, 0.3, 0.15, 0.02, 0.25, 0.4],
+          "rate_matrix": [[0, 1, 2, 1], [1, 0, 1, 2], [2, 1, 0, 1], [1, 2, 1, 0]],
+          "rate_divisor": "equilibrium_exit_rate", "root_prior": "equilibrium_distribution",
+          "gamma_rate_mixture": {"gamma_shape": 0.7, "gamma_categories": 3},
+          "character_definitions": np.vstack([np.eye(k), np.ones((1, k))]).tolist()}
+    f = tmp_path / "aln.u8"
+    f.write_bytes(codes.tobytes())
+    for fn, extra in ((arbplf.arbplf_ll, {"site_reduction": {"aggregation": "sum"}}),
+                      (arbplf.arbplf_ll, {"site_reduction": {"selection": [0, 17, 2999]}}),
+                      (arbplf.arbplf_deriv, {"site_reduction": {"aggregation": "avg"}}),
+                      (arbplf.arbplf_em_update, {"site_reduction": {"aggregation": "sum"}})):
+        a = dict(extra, model_and_data=dict(md, character_data=codes.tolist()))
+        b = dict(extra, model_and_data=dict(md, character_data_file=str(f)))
+        assert json.loads(fn(json.dumps(a))) == json.loads(fn(json.dumps(b)))

@@ -313,3 +313,39 @@ def test_json_numbers_and_unicode(validate):
     assert validate(s) == 0
     s2 = json.dumps(x).replace('"edges"', '"edges": [[0, 1]], "edges"')   # duplicate key: last wins
     assert validate(s2) == 0
+
+
+def test_character_data_file_side_channel(validate, tmp_path):
+    """binary side channel for large alignments (an extension of the reference's input):
+    'character_data_file' = raw [site][node] bytes, used with 'character_definitions'"""
+    x = copy.deepcopy(GOOD)
+    md = x["model_and_data"]
+    md.pop("probability_array", None)
+    md.pop("character_data", None)
+    N = len(md["edges"]) + 1
+    k = len(md["rate_matrix"])
+    md["character_definitions"] = [[1.0 if j == c else 0.0 for j in range(k)] for c in range(k)] + [[1.0] * k]
+    codes = bytes([(s * 7 + a) % (k + 1) for s in range(5) for a in range(N)])
+    f = tmp_path / "codes.u8"
+    f.write_bytes(codes)
+    md["character_data_file"] = str(f)
+    x.pop("site_reduction", None)
+    assert validate(x) == 0
+    bad = copy.deepcopy(x)
+    bad["model_and_data"]["character_data_file"] = str(tmp_path / "missing.u8")
+    assert validate(bad) != 0
+    (tmp_path / "ragged.u8").write_bytes(codes[:-1])
+    bad["model_and_data"]["character_data_file"] = str(tmp_path / "ragged.u8")
+    assert validate(bad) != 0
+    (tmp_path / "range.u8").write_bytes(codes[:-1] + bytes([k + 1]))
+    bad["model_and_data"]["character_data_file"] = str(tmp_path / "range.u8")
+    assert validate(bad) != 0
+    bad = copy.deepcopy(x)
+    bad["model_and_data"]["character_data"] = [[0] * N]
+    assert validate(bad) != 0                       # both forms at once
+    bad = copy.deepcopy(x)
+    del bad["model_and_data"]["character_definitions"]
+    assert validate(bad) != 0
+    bad = copy.deepcopy(x)
+    bad["model_and_data"]["character_data_file"] = 17
+    assert validate(bad) != 0
