@@ -59,3 +59,33 @@ def test_full_size_properties(eng, cfg):
     many, _ = eng.deriv(want_sums=False)
     eng.set_option(E.OPT_SITE_CHUNK, 0)
     assert np.array_equal(one, many)
+
+
+def test_cli_with_binary_alignment_file(eng, tmp_path):
+    """the whole operator path at scale: arbplf-ll reads 1M sites x 99 nodes from a character_data_file, compresses
+    identical patterns, uploads, evaluates, aggregates -- and must agree with the engine driven directly"""
+    import json
+    import os
+    import subprocess
+    from phyly_amd import synth
+    w = synth.Workload(2)
+    w.setup_engine(eng)
+    S = 1_000_000
+    block = w.simulate(200_000)
+    codes = np.ascontiguousarray(np.tile(block, (1, 5)))            # every pattern occurs (at least) five times
+    eng.set_patterns_codes(codes, w.defs)
+    eng.set_site_weights(None)
+    _, (hi, lo) = eng.ll(per_site=False)
+    f = tmp_path / "aln.u8"
+    np.ascontiguousarray(codes.T).tofile(f)                          # [site][node]
+    md = w.json_model(codes[:, :1])
+    del md["character_data"]
+    md["character_data_file"] = str(f)
+    q = {"model_and_data": md, "site_reduction": {"aggregation": "sum"}}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "phyly_amd", "csrc", "arbplf-ll")], input=json.dumps(q),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    out = json.loads(r.stdout)
+    assert out["columns"] == ["value"]
+    assert abs(out["data"][0][0] - (hi + lo)) <= 1e-12 * abs(hi + lo)
