@@ -1,0 +1,52 @@
+"""CPU: the host layer (JSON reader, validation, reductions, K0 set-up paths) under AddressSanitizer + UBSan.
+
+tests/sanitize_host.c links host_*.c with stubs in place of the GPU engine, validates every golden input of its
+kind, runs the driver entry point up to the (failing) engine call, and then feeds a few thousand byte-level
+mutations of those inputs through the same paths.  Any heap error, leak or undefined behaviour aborts the binary."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "phyly_amd", "csrc")
+EX = os.path.join(GOLDEN, "examples")
+
+
+@pytest.fixture(scope="module")
+def binary(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("san") / "sanitize_host")
+    srcs = [os.path.join(ROOT, "tests", "sanitize_host.c")] + sorted(glob.glob(os.path.join(CSRC, "host_*.c")))
+    cmd = ["gcc", "-O1", "-g", "-std=c11", "-D_GNU_SOURCE", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + srcs + ["-lquadmath", "-lm", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
+    return out
+
+
+def _files(kind):
+    pats = {"ll": ["*/in.json", "*/ll/in*.json"], "deriv": ["*/deriv/in.json", "JC.long.branch/*.json"],
+            "marginal": ["*/marginal/in.json"], "dwell": ["*/dwell/*/in.json", "BEAST.MarkovJumps/MarkovRewardsC/in.json"],
+            "trans": ["*/trans/*/in*.json", "BEAST.MarkovJumps/MarkovJumpsC/in*.json", "BEAST.MarkovJumps/MarkovMarginalRate/in*.json"],
+            "em_update": ["*/em-update/*/in.json"], "hess": ["*/hess/*/in.json"]}[kind]
+    out = []
+    for p in pats:
+        out += sorted(glob.glob(os.path.join(EX, p)))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["ll", "deriv", "marginal", "dwell", "trans", "em_update", "hess"])
+def test_host_layer_under_sanitizers(binary, kind):
+    files = _files(kind)
+    assert files
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
+    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")   # diagnostics echo mutated bytes
+    assert r.returncode == 0, (out[-500:], err[-3000:])
+    last = out.strip().splitlines()[-1].split()
+    assert last[0] == "files" and int(last[1]) == len(files)
+    assert int(last[3]) == len(files), "every golden input must validate: " + out[-300:]
