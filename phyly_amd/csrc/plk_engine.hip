@@ -108,6 +108,13 @@ struct plk_engine {
     double *d_frag = nullptr; size_t frag_cap = 0;   /* MFMA A fragments */
     double *d_root_wd = nullptr;         /* root weights, distributed layout */
     int4 *d_mops = nullptr;              /* MFMA program (observation ops chained for the value prefetch) */
+    double *d_exL = nullptr, *d_exF = nullptr;   /* edge expectations: directions, scaled Frechet matrices */
+    int *d_exmask = nullptr;
+    dd *d_exscr = nullptr;
+    size_t exL_cap = 0, exF_cap = 0, exmask_cap = 0, exscr_cap = 0;
+    int *d_u4pack = nullptr;             /* k = 4 down / up passes: the call's integer tables, one block */
+    double *d_u4tip = nullptr;           /* ... and its tip / edge-form tip tables */
+    size_t u4pack_cap = 0, u4tip_cap = 0;
     int mfma_first_slot = -1, mfma_first_row = 0;
     bool mfma_dirty = true;
     size_t ps_cap = 0, tip_cap = 0;
@@ -967,7 +974,7 @@ extern "C" void plk_destroy(plk_engine *h)
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
                     h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
-                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_u4pack, h->d_u4tip, h->d_exL, h->d_exF, h->d_exmask, h->d_exscr, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1890,22 +1897,32 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         if (prev >= 0) { ops2[prev].z = first_slot2 | (1 << 30); ops2[prev].w = first_row2; }
     }
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
-    auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_oe2, d_obs2, d_ops2, d_inl, d_tip4, d_dtip4};
-        for (void *p : ps) if (p) (void)hipFree(p);
-    };
+    auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
-    if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)std::max(E, 1))) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)std::max(E, 1))) ||
-        (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
-        (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
-        (rc = dev_upload(h, &d_ops2, ops2.data(), ops2.size())) || (rc = dev_upload(h, &d_oe2, h->op_edge.data(), h->op_edge.size())) ||
-        (rc = dev_upload(h, &d_obs2, h->obs_nodes.data(), h->obs_nodes.size())) ||
-        (rc = dev_upload(h, &d_inl, node_inline.data(), (size_t)N)) ||
-        (rc = dev_alloc(h, &d_tip4, ntab)) || (rc = dev_alloc(h, &d_dtip4, ntab * nM))) { cleanup(); return rc; }
-    if (edge_mask && E > 0 && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
-    if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
-    if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
-    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
+    {
+        /* all small integer tables of this call in one host block, one upload */
+        if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+        std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end());
+        std::vector<int> pack;
+        auto put = [&](const int *src, size_t n) { const size_t off = pack.size(); pack.insert(pack.end(), src, src + n); while (pack.size() % 4) pack.push_back(0); return off; };
+        const size_t o_ops = put(reinterpret_cast<const int *>(ops2.data()), ops2.size() * 4);
+        const size_t o_et = put(edge_tip.data(), (size_t)E), o_ei = put(edge_int.data(), (size_t)E), o_ni = put(node_int.data(), (size_t)N);
+        const size_t o_te = put(te.data(), te.size()), o_has = put(hd.data(), (size_t)N), o_ns = put(node_scale.data(), (size_t)N);
+        const size_t o_oe = put(h->op_edge.data(), h->op_edge.size()), o_obs = put(h->obs_nodes.data(), h->obs_nodes.size());
+        const size_t o_inl = put(node_inline.data(), (size_t)N);
+        const size_t o_em = edge_mask && E > 0 ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
+        if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4))) return rc;
+        if ((rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, ntab * (size_t)(1 + nM)))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->d_u4pack, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));      /* pack is a local */
+        int *b = h->d_u4pack;
+        d_ops2 = reinterpret_cast<int4 *>(b + o_ops);
+        d_et = b + o_et; d_ei = b + o_ei; d_ni = b + o_ni; d_te = b + o_te; d_has = b + o_has; d_ns = b + o_ns;
+        d_oe2 = b + o_oe; d_obs2 = b + o_obs; d_inl = b + o_inl;
+        d_emask = edge_mask && E > 0 ? b + o_em : nullptr;
+        d_nmask = node_mask ? b + o_nm : nullptr;
+        d_tip4 = h->d_u4tip; d_dtip4 = h->d_u4tip + ntab;
+    }
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
                        E, ntips + 1, h->nchar, d_te, h->d_Pdd, h->d_defs, d_tip4);
     for (int m = 0; m < nM; m++)
@@ -2142,38 +2159,40 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
     const size_t kk = (size_t)k * k, n2 = 4 * kk;
     /* how many directions one pass of the kernels can carry */
     const int per_pass = use_updown4(h) && !use_mfma(h) ? 4 : 1;
-    double *d_L = nullptr, *d_F = nullptr;
-    int *d_mask = nullptr;
-    dd *d_scr = nullptr;
-    auto cleanup = [&]() {
-        if (d_L) (void)hipFree(d_L);
-        if (d_F) (void)hipFree(d_F);
-        if (d_mask) (void)hipFree(d_mask);
-        if (d_scr) (void)hipFree(d_scr);
-    };
-    if ((rc = dev_alloc(h, &d_L, 2 * kk)) || (rc = dev_alloc(h, &d_F, (size_t)per_pass * C * E * kk))) { cleanup(); return rc; }
-    if (edge_mask && (rc = dev_upload(h, &d_mask, edge_mask, (size_t)E))) { cleanup(); return rc; }
+    /* grow-only engine buffers: no per-call hipMalloc / hipFree */
+    auto cleanup = [&]() {};
     const size_t lds_bytes = 4 * n2 * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * 4 * n2))) { cleanup(); return rc; }
+    if ((rc = dev_reserve(h, &h->d_exL, &h->exL_cap, (size_t)per_pass * 2 * kk)) ||
+        (rc = dev_reserve(h, &h->d_exF, &h->exF_cap, (size_t)per_pass * C * E * kk)) ||
+        (rc = dev_reserve(h, &h->d_exmask, &h->exmask_cap, (size_t)E)) ||
+        (!use_lds && (rc = dev_reserve(h, &h->d_exscr, &h->exscr_cap, (size_t)C * E * 4 * n2)))) return rc;
+    double *d_L = h->d_exL, *d_F = h->d_exF;
+    int *d_mask = nullptr;
+    dd *d_scr = h->d_exscr;
+    if (edge_mask) {
+        HIPCHK(h, hipMemcpyAsync(h->d_exmask, edge_mask, (size_t)E * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        d_mask = h->d_exmask;
+    }
     const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
-    std::vector<double> L(2 * kk), tmp_site, tmp_sums;
+    std::vector<double> L((size_t)per_pass * 2 * kk), tmp_site, tmp_sums;
     for (int m0 = 0; m0 < nL; m0 += per_pass) {
         const int nm = std::min(per_pass, nL - m0);
         for (int m = 0; m < nm; m++) {
-            std::copy(L_hi + (size_t)(m0 + m) * kk, L_hi + (size_t)(m0 + m + 1) * kk, L.begin());
-            if (L_lo) std::copy(L_lo + (size_t)(m0 + m) * kk, L_lo + (size_t)(m0 + m + 1) * kk, L.begin() + kk);
-            else std::fill(L.begin() + kk, L.end(), 0.0);
-            hipError_t e = hipMemcpyAsync(d_L, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
-                                   k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
-                                   d_scr, use_lds, d_L, coef_mode, d_mask, d_F + (size_t)m * C * E * kk);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      /* L is reused for the next direction */
-            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_edge_expect: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+            double *Lm = L.data() + (size_t)m * 2 * kk;
+            std::copy(L_hi + (size_t)(m0 + m) * kk, L_hi + (size_t)(m0 + m + 1) * kk, Lm);
+            if (L_lo) std::copy(L_lo + (size_t)(m0 + m) * kk, L_lo + (size_t)(m0 + m + 1) * kk, Lm + kk);
+            else std::fill(Lm + kk, Lm + 2 * kk, 0.0);
         }
+        HIPCHK(h, hipStreamSynchronize(h->stream));          /* the previous pass may still read d_L */
+        HIPCHK(h, hipMemcpyAsync(d_L, L.data(), (size_t)nm * 2 * kk * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        for (int m = 0; m < nm; m++) {
+            hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+                               k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
+                               d_scr, use_lds, d_L + (size_t)m * 2 * kk, coef_mode, d_mask, d_F + (size_t)m * C * E * kk);
+        }
+        if (hipGetLastError() != hipSuccess) { h->err = "plk_edge_expect: Frechet kernel launch failed"; return PLK_E_DEVICE; }
+        HIPCHK(h, hipStreamSynchronize(h->stream));          /* L is a host local */
         /* outputs of this pass: [S][nm*E] and [nm*E][2]; scattered into [S][nL*E] / [nL*E][2] */
         double *so = nullptr, *su = nullptr;
         if (site_out) { if (nm == nL) so = site_out; else { tmp_site.assign((size_t)S * nm * E, 0.0); so = tmp_site.data(); } }
