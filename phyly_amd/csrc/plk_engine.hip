@@ -1698,9 +1698,13 @@ static int wsum_rows(plk_engine *h, int rows, long n, const double *X, const dou
 }
 
 template <int T>
-static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, unsigned grid, size_t lds, bool deriv, bool marg)
+static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, const MDownProg &pg, unsigned grid, size_t lds, bool deriv, bool marg)
 {
-    hipLaunchKernelGGL(k_down_store_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    const size_t lds_down = lds + (size_t)pg.nobs * MF_SITES;
+    if (lds_down <= 60 * 1024 && (a.s0 % MF_SITES) == 0)
+        hipLaunchKernelGGL(k_down_fused_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds_down, h->stream, a, pg);
+    else
+        hipLaunchKernelGGL(k_down_store_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
     if (deriv && marg) hipLaunchKernelGGL((k_up_mfma<T, true, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
     else if (deriv) hipLaunchKernelGGL((k_up_mfma<T, true, false>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
     else hipLaunchKernelGGL((k_up_mfma<T, false, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
@@ -1730,16 +1734,33 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
     int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr, *d_ns = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr, *d_obsm = nullptr;
+    int4 *d_dops = nullptr;
+    /* program of the depth-first down pass (k_down_fused_mfma) */
+    std::vector<int4> dops(h->ops.size());
+    {
+        std::vector<int> row(N, -1);
+        for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
+        for (size_t pc = 0; pc < h->ops.size(); pc++) {
+            const int code = h->ops[pc].x & 0xff;
+            int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
+            if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) o.y = row[h->ops[pc].y];
+            else if (code == OP_MATVEC) { o.y = h->op_edge[pc]; o.z = node_int[h->indices[o.y]]; o.w = edge_int[o.y]; }
+            else if (code == OP_SCALE) o.y = node_scale[h->ops[pc].y];
+            dops[pc] = o;
+        }
+    }
+    const int nslots_m = std::max(h->slots_needed, 1);
     double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
+        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_obsm, d_dops, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)E)) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)E)) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
         (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) || (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
+        (rc = dev_upload(h, &d_dops, dops.data(), dops.size())) || (rc = dev_upload(h, &d_obsm, h->obs_nodes.data(), h->obs_nodes.size())) ||
         (rc = dev_alloc(h, &d_fP, nfr)) || (rc = dev_alloc(h, &d_fPT, nfr)) || (rc = dev_alloc(h, &d_fD, nfr)) ||
         (rc = dev_alloc(h, &d_tipd, ntab)) || (rc = dev_alloc(h, &d_dtip, ntab))) { cleanup(); return rc; }
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
@@ -1755,7 +1776,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
                        k, R, E, ntips, h->nchar, d_te, d_M, h->d_defs, h->K, d_dtip, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)nslots_m * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -1785,6 +1806,9 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         a.LN = p; p += (size_t)nin * C * R * a.stride;
         a.FN = p; p += (size_t)nin * C * R * a.stride;
         a.node_scale = d_ns;
+        MDownProg pg;
+        pg.ops = d_dops; pg.nops = (int)dops.size(); pg.nobs = (int)h->obs_nodes.size(); pg.obs_nodes = d_obsm;
+        pg.slots = p; p += (size_t)nslots_m * R * a.stride;
         a.SC = p; p += (size_t)nsc * C * n;
         a.CW = p; p += (size_t)C * n;
         a.XC = p; p += (size_t)C * n;
@@ -1794,10 +1818,10 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
-        if (T == 1) launch_updown_mfma<1>(h, a, grid, lds, deriv, marg);
-        else if (T == 2) launch_updown_mfma<2>(h, a, grid, lds, deriv, marg);
-        else if (T == 3) launch_updown_mfma<3>(h, a, grid, lds, deriv, marg);
-        else launch_updown_mfma<4>(h, a, grid, lds, deriv, marg);
+        if (T == 1) launch_updown_mfma<1>(h, a, pg, grid, lds, deriv, marg);
+        else if (T == 2) launch_updown_mfma<2>(h, a, pg, grid, lds, deriv, marg);
+        else if (T == 3) launch_updown_mfma<3>(h, a, pg, grid, lds, deriv, marg);
+        else launch_updown_mfma<4>(h, a, pg, grid, lds, deriv, marg);
         if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;

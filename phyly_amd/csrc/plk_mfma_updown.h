@@ -199,6 +199,129 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
     }
 }
 
+/*
+ * The down pass as a depth-first traversal of the post-order program (the structure of k_ll_mfma): the vector under
+ * construction stays in registers, waiting vectors go to HBM stack slots, and every internal node vector L_a and
+ * internal edge vector Ev_e is written exactly once, at the OP_MATVEC that consumes / produces it.  Program (int4):
+ * observation ops y = staged code row; OP_MATVEC y = CSR edge, z = storage index of the child node, w = storage
+ * index of the edge; OP_PUSH / OP_POPMUL y = stack slot; OP_SCALE y = rescaling slot or -1.
+ */
+struct MDownProg {
+    const int4 *ops;
+    int nops, nobs;
+    const int *obs_nodes;
+    double *slots;                /* [nslots][R][stride] */
+};
+
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_down_fused_mfma(MUpArgs a, MDownProg pg)
+{
+    extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles, then nobs x 64 staged pattern codes */
+    constexpr int R = 4 * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const long sl = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;
+    const int nfrag = T * a.kk4 * 64;
+    const int NT = a.ntips + 1;
+    const size_t n = (size_t)a.n;
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_frag + nfrag);
+    {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
+        for (int idx = tid; idx < pg.nobs * (MF_SITES / 4); idx += MF_BLOCK) {
+            const int row = idx / (MF_SITES / 4), col = idx - row * (MF_SITES / 4);
+            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)pg.obs_nodes[row] * a.Spad + a.s0 +
+                                                          (size_t)blockIdx.x * MF_SITES)[col];
+        }
+    }
+    __syncthreads();
+    const int scol = wave * 16 + (lane & 15);
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(pg.ops));
+    const int root_int = as_uniform(a.node_int)[as_uniform(a.preorder)[0]];
+    int xmax = INT_MIN;
+    for (int c = 0; c < a.C; c++) {
+        const double *tipc = a.tip + (size_t)c * NT * a.nchar * 4 * R;
+        double x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = (g + 4 * r < a.k) ? 1.0 : 0.0;
+        int X = 0;
+        for (int pc = 0; pc < pg.nops; pc++) {
+            const int ox = ops[4 * pc], oy = ops[4 * pc + 1];
+            const int code = ox & 0xff;
+            if (code == OP_MATVEC) {
+                const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
+                mf_store<R>(a.LN + ((size_t)oz * a.C + c) * R * a.stride, a.stride, lin, x);
+                mf_stage(lds_frag, a.fragP + ((size_t)c * a.E + oy) * nfrag, nfrag, tid);
+                double m[R], x0;
+                mf_matvec<T>(lds_frag, a.kk4, lane, x, m);
+                if (mf_is_const<R>(x, g, a.k, x0)) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) m[r] = (g + 4 * r < a.k) ? x0 : 0.0;
+                }
+                mf_store<R>(a.EV + ((size_t)ow * a.C + c) * R * a.stride, a.stride, lin, m);
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = m[r];
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
+                double v[R];
+                mf_gather<R>(tipc, a.nchar, t, code_lds[oy * MF_SITES + scol], g, v);
+                if (code == OP_TIP_SET) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[r] = v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[r] *= v[r];
+                }
+            } else if (code == OP_PUSH) {
+                mf_store<R>(pg.slots + (size_t)oy * R * a.stride, a.stride, lin, x);
+            } else if (code == OP_POPMUL) {
+                double v[R];
+                mf_load<R>(pg.slots + (size_t)oy * R * a.stride, a.stride, lin, v);
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] *= v[r];
+            } else if (code == OP_SCALE) {
+                if (oy >= 0) {
+                    double mx = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) mx = fmax(mx, x[r]);
+                    mx = fmax(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmax(mx, __shfl_xor(mx, 32, 64));
+                    double sc = 1.0;
+                    if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                        const int e = ilogb(mx);
+                        sc = ldexp(1.0, -e);
+#pragma unroll
+                        for (int r = 0; r < R; r++) x[r] *= sc;
+                        X += e;
+                    }
+                    if (valid && g == 0) a.SC[((size_t)oy * a.C + c) * n + sl] = sc;
+                }
+            }
+        }
+        mf_store<R>(a.LN + ((size_t)root_int * a.C + c) * R * a.stride, a.stride, lin, x);
+        double lh_c = 0.0;
+        const double *rw = a.root_wd + g * R;
+#pragma unroll
+        for (int r = 0; r < R; r++) lh_c = fma(rw[r], x[r], lh_c);
+        lh_c += __shfl_xor(lh_c, 16, 64);
+        lh_c += __shfl_xor(lh_c, 32, 64);
+        lh_c *= as_uniform(a.cat_prior)[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid && g == 0) { a.XC[(size_t)c * n + sl] = (double)X; a.CW[(size_t)c * n + sl] = lh_c; }
+    }
+    if (xmax == INT_MIN) xmax = 0;
+    if (valid && g == 0) {
+        double lh_total = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + slc] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + slc], w, lh_total);
+            a.CW[(size_t)c * n + slc] = w;
+        }
+        a.LH[sl] = lh_total;
+    }
+}
+
 template <int T, bool DERIV, bool MARG>
 __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_up_mfma(MUpArgs a)
 {
