@@ -193,3 +193,30 @@ def test_random_inputs_match_oracle(oracle, kind):
         _check(kind, got, want)
         done += 1
     assert done >= 40, (done, skipped)
+
+
+@pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 25, 32, 33, 48, 64])
+def test_medium_and_large_state_spaces(oracle, k):
+    """state counts that exercise every padded width of the register-resident vector kernel (K = 16, 20, 32) and of
+    the matrix-core kernels (T = 1..4 row tiles), through the JSON API with compact character data"""
+    import arbplf
+    rng = random.Random(1000 + k)
+    n_nodes = 9
+    edges = random_tree(rng, n_nodes)
+    Q = [[0 if i == j else rng.random() + 0.05 for j in range(k)] for i in range(k)]
+    nchar = k + 2
+    defs = [[1.0 if j == c else 0.0 for j in range(k)] for c in range(k)] + [[1.0] * k] + \
+           [[1.0 if j % 3 == 0 else 0.0 for j in range(k)]]
+    S = 12
+    data = [[rng.randrange(nchar) if rng.random() < 0.7 else k for _ in range(n_nodes)] for _ in range(S)]
+    md = {"edges": edges, "edge_rate_coefficients": [rng.random() * 0.5 + 0.01 for _ in edges], "rate_matrix": Q,
+          "rate_divisor": "equilibrium_exit_rate", "root_prior": "equilibrium_distribution",
+          "character_definitions": defs, "character_data": data,
+          "rate_mixture": {"rates": [0.3, 1.7], "prior": [0.4, 0.6]}}
+    for kind, prod, orc in (("ll", arbplf.arbplf_ll, oracle.arbplf_ll), ("deriv", arbplf.arbplf_deriv, oracle.arbplf_deriv),
+                            ("marginal", arbplf.arbplf_marginal, oracle.arbplf_marginal)):
+        s = json.dumps({"model_and_data": md})
+        want = json.loads(orc(s))
+        if any(not np.isfinite(r[-1]) for r in want["data"]):
+            pytest.skip("zero-likelihood site drawn")
+        _check(kind, json.loads(prod(s)), want)
