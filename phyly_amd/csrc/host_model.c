@@ -160,6 +160,41 @@ static int parse_probability_array(host_model *m, const jval *pa)
         for (int a = 0; a < N; a++)
             if (nonneg_array(m->prob + ((size_t)s * N + a) * k, k, j_at(x, a), name)) return -1;
     }
+    /* Compact form ("character_data fast path"): real probability arrays consist of a handful of
+     * distinct rows (one-hot states, all-ones "missing", a few ambiguity sets).  When there are at most 256 of them,
+     * the array is re-expressed as character codes + definitions -- bitwise the same observation vectors -- so that
+     * the compact device layout (1 byte per node and site), the tip tables and the fused kernels apply.
+     * Opt-in (ARBPLF_COMPACT_DENSE=1) in this round: the default keeps the dense layout the parity suite was run on. */
+    const char *compact_env = getenv("ARBPLF_COMPACT_DENSE");
+    if (S * (long)N > 0 && compact_env && compact_env[0] == '1') {
+        const size_t rows = (size_t)S * N, rb = (size_t)k * sizeof(double);
+        uint8_t *codes = malloc(rows + 1);
+        double *defs = malloc(256 * rb + 1);
+        int table[1024];
+        int nchar = 0, ok = codes && defs;
+        for (int i = 0; i < 1024; i++) table[i] = -1;
+        for (size_t r = 0; ok && r < rows; r++) {
+            const unsigned char *row = (const unsigned char *)(m->prob + r * k);
+            unsigned long long hsh = 1469598103934665603ULL;
+            for (size_t b = 0; b < rb; b++) { hsh ^= row[b]; hsh *= 1099511628211ULL; }
+            size_t pos = (size_t)hsh & 1023;
+            int found = -1;
+            while (table[pos] >= 0) {
+                if (!memcmp(defs + (size_t)table[pos] * k, row, rb)) { found = table[pos]; break; }
+                pos = (pos + 1) & 1023;
+            }
+            if (found < 0) {
+                if (nchar == 256) { ok = 0; break; }
+                memcpy(defs + (size_t)nchar * k, row, rb);
+                table[pos] = found = nchar++;
+            }
+            codes[r] = (uint8_t)found;
+        }
+        if (ok) {
+            free(m->prob); m->prob = NULL;
+            m->codes8 = codes; m->defs = defs; m->nchar = nchar;
+        } else { free(codes); free(defs); }
+    }
     return 0;
 }
 

@@ -13,23 +13,62 @@
 #include "arbplf.h"
 #include "plk.h"
 
-/* ---- engine stubs: no GPU in the sanitizer build ---- */
+/* ---- engine stand-in: no GPU in the sanitizer build.  With FAKE_ENGINE=1 in the environment the entry points
+ * succeed and fill their outputs with constants of the documented shapes, so that the drivers' table code runs under
+ * the sanitizers; otherwise plk_create fails and the drivers' error paths run. ---- */
+struct plk_engine { int N, E, k, C; long S; };
+static struct plk_engine g_fake;
+static int fake_on(void) { const char *e = getenv("FAKE_ENGINE"); return e && *e == '1'; }
 const char *plk_create_error(void) { return "stub: no engine in the sanitizer build"; }
-int plk_create(plk_engine **out, int device) { (void)device; *out = NULL; return PLK_E_DEVICE; }
+int plk_create(plk_engine **out, int device) { (void)device; if (!fake_on()) { *out = NULL; return PLK_E_DEVICE; } *out = &g_fake; return PLK_OK; }
 void plk_destroy(plk_engine *h) { (void)h; }
 const char *plk_last_error(const plk_engine *h) { (void)h; return "stub"; }
-int plk_set_tree(plk_engine *h, int N, const int *a, const int *b, const int *c) { (void)h; (void)N; (void)a; (void)b; (void)c; return PLK_E_DEVICE; }
+int plk_set_tree(plk_engine *h, int N, const int *a, const int *b, const int *c) { (void)a; (void)b; (void)c; h->N = N; h->E = N - 1; return PLK_OK; }
 int plk_set_model(plk_engine *h, int k, int C, const double *a, const double *b, const double *c, const double *d,
-                  const double *e, int m, const double *f) { (void)h; (void)k; (void)C; (void)a; (void)b; (void)c; (void)d; (void)e; (void)m; (void)f; return PLK_E_DEVICE; }
-int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *c, int w, int n, const double *d) { (void)h; (void)S; (void)c; (void)w; (void)n; (void)d; return PLK_E_DEVICE; }
-int plk_set_patterns_dense(plk_engine *h, long S, const double *B, int w) { (void)h; (void)S; (void)B; (void)w; return PLK_E_DEVICE; }
-int plk_set_site_weights(plk_engine *h, const double *w, int where) { (void)h; (void)w; (void)where; return PLK_E_DEVICE; }
-int plk_ll(plk_engine *h, double *o, int w, double *s) { (void)h; (void)o; (void)w; (void)s; return PLK_E_DEVICE; }
-int plk_deriv(plk_engine *h, const int *m, double *o, double *s) { (void)h; (void)m; (void)o; (void)s; return PLK_E_DEVICE; }
-int plk_marginal(plk_engine *h, const int *m, double *o, double *s) { (void)h; (void)m; (void)o; (void)s; return PLK_E_DEVICE; }
+                  const double *e, int m, const double *f) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)m; (void)f; h->k = k; h->C = C; return PLK_OK; }
+int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *c, int w, int n, const double *d)
+{
+    (void)w;
+    unsigned long long acc = 0;                                   /* read every byte the driver promised */
+    for (long i = 0; i < S * h->N; i++) acc += c[i];
+    for (int i = 0; i < n * h->k; i++) acc += (unsigned long long)d[i];
+    h->S = S;
+    return acc == ~0ULL ? PLK_E_ARG : PLK_OK;
+}
+int plk_set_patterns_dense(plk_engine *h, long S, const double *B, int w)
+{
+    (void)w;
+    double acc = 0;
+    for (long i = 0; i < S * h->N * h->k; i++) acc += B[i];
+    h->S = S;
+    return acc < 0 ? PLK_E_ARG : PLK_OK;
+}
+int plk_set_site_weights(plk_engine *h, const double *w, int where) { (void)where; double a = 0; if (w) for (long i = 0; i < h->S; i++) a += w[i]; return a != a ? PLK_E_ARG : PLK_OK; }
+int plk_ll(plk_engine *h, double *o, int w, double *s) { (void)w; if (o) for (long i = 0; i < h->S; i++) o[i] = -1.5; if (s) { s[0] = -1.5 * h->S; s[1] = 0; } return PLK_OK; }
+int plk_deriv(plk_engine *h, const int *m, double *o, double *s)
+{
+    double a = 0; if (m) for (int i = 0; i < h->E; i++) a += m[i];
+    if (o) for (long i = 0; i < h->S * h->E; i++) o[i] = 0.25;
+    if (s) for (int i = 0; i < 2 * h->E; i++) s[i] = 0.5;
+    return a < 0 ? PLK_E_ARG : PLK_OK;
+}
+int plk_marginal(plk_engine *h, const int *m, double *o, double *s)
+{
+    double a = 0; if (m) for (int i = 0; i < h->N; i++) a += m[i];
+    if (o) for (long i = 0; i < h->S * h->N * h->k; i++) o[i] = 0.125;
+    if (s) for (int i = 0; i < 2 * h->N * h->k; i++) s[i] = 0.5;
+    return a < 0 ? PLK_E_ARG : PLK_OK;
+}
 int plk_edge_expect_multi(plk_engine *h, int n, const double *a, const double *b, int c, const int *m, double *o, double *s)
-{ (void)h; (void)n; (void)a; (void)b; (void)c; (void)m; (void)o; (void)s; return PLK_E_DEVICE; }
-int plk_hess(plk_engine *h, double *o) { (void)h; (void)o; return PLK_E_DEVICE; }
+{
+    double acc = 0; (void)c;
+    for (int i = 0; i < n * h->k * h->k; i++) acc += a[i] + (b ? b[i] : 0);
+    if (m) for (int i = 0; i < h->E; i++) acc += m[i];
+    if (o) for (long i = 0; i < h->S * n * h->E; i++) o[i] = 0.75;
+    if (s) for (int i = 0; i < 2 * n * h->E; i++) s[i] = 0.5;
+    return acc != acc ? PLK_E_ARG : PLK_OK;
+}
+int plk_hess(plk_engine *h, double *o) { for (int i = 0; i < 2 * h->E * h->E; i++) o[i] = -2.0; return PLK_OK; }
 
 static char *slurp(const char *path, size_t *n)
 {

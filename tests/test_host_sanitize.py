@@ -44,9 +44,32 @@ def test_host_layer_under_sanitizers(binary, kind):
     files = _files(kind)
     assert files
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for fake in ("0", "1"):       # 0: the engine fails (error paths); 1: a stand-in engine succeeds (table-writing paths)
+        r = subprocess.run([binary, kind] + files, capture_output=True, env=dict(env, FAKE_ENGINE=fake), timeout=600)
+        out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")   # diagnostics echo mutated bytes
+        assert r.returncode == 0, (fake, out[-500:], err[-3000:])
+        last = out.strip().splitlines()[-1].split()
+        assert last[0] == "files" and int(last[1]) == len(files)
+        assert int(last[3]) == len(files), "every golden input must validate: " + out[-300:]
+
+
+@pytest.mark.parametrize("kind,seed", [("ll", 11), ("deriv", 22), ("marginal", 33)])
+def test_random_queries_under_sanitizers(binary, tmp_path, kind, seed):
+    """the seeded random queries of tests/test_gpu_differential.py (multifurcating trees, duplicate selections,
+    weighted aggregations, both observation forms) through the drivers with the stand-in engine"""
+    import json
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_differential import random_model
+    rng = random.Random(seed)
+    files = []
+    for i in range(70):
+        f = tmp_path / ("q%03d.json" % i)
+        f.write_text(json.dumps(random_model(rng, kind)))
+        files.append(str(f))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               FAKE_ENGINE="1")
     r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
-    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")   # diagnostics echo mutated bytes
+    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
     assert r.returncode == 0, (out[-500:], err[-3000:])
-    last = out.strip().splitlines()[-1].split()
-    assert last[0] == "files" and int(last[1]) == len(files)
-    assert int(last[3]) == len(files), "every golden input must validate: " + out[-300:]
