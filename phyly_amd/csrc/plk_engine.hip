@@ -1,25 +1,27 @@
 /*
  * plk_engine.hip -- MI355X (gfx950) pruning-likelihood engine behind include/plk.h.
  *
- * Kernels (all fp64; see DESIGN.md for layouts and rooflines):
- *   k_expm_dd        P[c][e] = exp(Qn * r_c * t_e) in double-double arithmetic,
- *                    one workgroup per (c, e); replaces arb_mat_exp in
- *                    src/cross_site_ws.c:151-168 of the reference.
- *   k_build_stream   gathers the rounded P matrices into traversal-program order
- *   k_build_tip      tip tables P_e * defs[code] for leaf edges (k = 4 fused path)
- *   k_ll_fused4      fused post-order traversal, one site per lane, partial vectors
- *                    in a register stack, P matrices as scalar (SGPR) operands,
- *                    tip tables + pattern codes staged in LDS; replaces the
- *                    site x category x node loops of src/arbplfll.c:139-170 +
- *                    src/evaluate_site_lhood.c:21-57 + src/util.c:242-301.
- *   k_ll_generic<K>  the same traversal program for any k <= 64 with the
- *                    stack slots resident in HBM ([slot][state][site], site fastest).
- *   k_down_store<K>, k_up<K>   down pass with stored edge/node vectors and the
- *                    BFS-order up pass for edge derivatives and marginals
- *                    (src/evaluate_site_forward.c:32-105, src/arbplfderiv.c:112-371,
- *                    src/arbplfmarginal.c:111-264).
- *   k_wsum_*         deterministic double-double weighted reductions over sites
- *                    (src/ndaccum.c:198-254 for aggregated site axes).
+ * Kernels (all fp64; see DESIGN.md for layouts and rooflines).  In this file:
+ *   k_expm_dd<F>     P[c][e] = exp(Qn * r_c * t_e) in double-double arithmetic, one workgroup per (c, e);
+ *                    replaces arb_mat_exp in src/cross_site_ws.c:151-168.  F = true: the 2k x 2k block
+ *                    exponential whose top-right block is the Frechet matrix (src/util.c:501-548).
+ *   k_build_*        P gathered into traversal-program order, tip tables P_e * defs[code]
+ *   k_ll_generic<K>  post-order traversal program for any k <= 64, stack slots in HBM
+ *   k_down_store<K>, k_up<K>   down pass with stored vectors + BFS up pass (deriv, marginal, edge
+ *                    expectations, Hessian rows) for dense observations and small k
+ *   k_wsum_rows, k_dd_final, k_gram   deterministic double-double reductions over sites
+ *                    (src/ndaccum.c:198-254 for aggregated site axes)
+ * and in the included headers:
+ *   plk_fused4_asm.h   k_ll_fused4_asm: the k = 4 headline kernel, interpreter in CDNA4 assembly
+ *                      (src/arbplfll.c:139-170 x src/evaluate_site_lhood.c:21-57 x src/util.c:242-301)
+ *   plk_fused4_asm2.h  the same with two sites per lane (option)      plk_fused4.h  the C++ variant
+ *   plk_updown4.h      k_down_fused4 / k_down_store4 / k_up4: k = 4 deriv, marginal, expectations
+ *                      (src/evaluate_site_forward.c:32-105, src/arbplfderiv.c:112-371,
+ *                      src/arbplfmarginal.c:111-264, src/evaluate_site_frechet.c:5-42)
+ *   plk_vec.h          k_ll_vec: 9 <= k <= 32 on the vector pipe
+ *   plk_mfma.h, plk_mfma_updown.h   fp64 matrix-core kernels for k up to 64
+ * Host side of the engine: model / pattern set-up, program builder (Sethi-Ullman ordered post-order),
+ * plk_ll / plk_deriv / plk_marginal / plk_edge_expect(_multi) / plk_fit_edge_rates / plk_hess.
  *
  * There is no CPU path in this file: every entry point needs a HIP device.
  */
