@@ -2,8 +2,9 @@
  * host_model.c -- JSON -> host_model validation (host C, product code).
  *
  * Reproduces which inputs the reference accepts and rejects
- * (src/parsemodel.c, src/parsereduction.c, src/csr_graph.c), with our own
- * diagnostics on stderr.  Behaviours the reference leaves unpinned
+ * (src/parsemodel.c, src/parsereduction.c, src/csr_graph.c); the diagnostics on
+ * stderr are this build's own wording, keyed by the JSON field at fault (stderr
+ * text is not part of the drop-in contract: only the exit status is).  Behaviours the reference leaves unpinned
  *  are rejected: non-positive gamma_categories / gamma_shape,
  * invariable_prior outside [0, 1), a rate_mixture prior that is neither a
  * string nor an array, an empty alignment.
@@ -35,13 +36,13 @@ int host_check_keys(const jval *obj, const char *const *required, const char *co
 /* src/parsemodel.c:26-75 */
 static int nonneg_array(double *dest, int n, const jval *a, const char *what)
 {
-    if (!j_is_array(a)) FAILF("%s: not an array\n", what);
-    if ((int)j_len(a) != n) FAILF("%s: unexpected array length (actual: %d desired: %d)\n", what, (int)j_len(a), n);
+    if (!j_is_array(a)) FAILF("error: %s must be an array of numbers\n", what);
+    if ((int)j_len(a) != n) FAILF("error: %s has %d entries where %d are needed\n", what, (int)j_len(a), n);
     for (int i = 0; i < n; i++) {
         const jval *x = j_at(a, i);
-        if (!j_is_number(x)) FAILF("%s: not a number\n", what);
+        if (!j_is_number(x)) FAILF("error: %s holds something that is not a number\n", what);
         double d = j_number(x);
-        if (d < 0) FAILF("%s: array entries must be nonnegative\n", what);
+        if (d < 0) FAILF("error: %s holds a negative number\n", what);
         dest[i] = d;
     }
     return 0;
@@ -60,7 +61,7 @@ void host_model_clear(host_model *m)
 /* src/parsemodel.c:211-368 + src/csr_graph.c:103-229 */
 static int parse_edges(host_model *m, const jval *edges)
 {
-    if (!j_is_array(edges)) FAILF("_validate_edges: not an array\n");
+    if (!j_is_array(edges)) FAILF("error: edges: a list of [parent, child] pairs is required\n");
     const int E = (int)j_len(edges), N = E + 1;
     int rc = -1;
     int *indeg = calloc(N, sizeof(int)), *outdeg = calloc(N, sizeof(int));
@@ -70,21 +71,21 @@ static int parse_edges(host_model *m, const jval *edges)
     for (int i = 0; i < E; i++) {
         const jval *e = j_at(edges, i);
         if (!j_is_array(e) || j_len(e) != 2 || !j_is_int(j_at(e, 0)) || !j_is_int(j_at(e, 1))) {
-            fprintf(stderr, "_validate_edges: each edge must be an array of two integers\n"); goto done;
+            fprintf(stderr, "error: edges: every entry must be a pair [parent, child] of integers\n"); goto done;
         }
         long long a = j_at(e, 0)->u.i, b = j_at(e, 1)->u.i;
         if (a < 0 || a >= N || b < 0 || b >= N) {
-            fprintf(stderr, "_validate_edges: node indices must be integers no less than 0 and no greater than the number of edges\n"); goto done;
+            fprintf(stderr, "error: edges: with E edges the node ids are 0..E\n"); goto done;
         }
-        if (a == b) { fprintf(stderr, "_validate_edges: edges cannot be loops\n"); goto done; }
+        if (a == b) { fprintf(stderr, "error: edges: an edge joins a node to itself\n"); goto done; }
         pa[i] = (int)a; pb[i] = (int)b;
         outdeg[a]++; indeg[b]++;
     }
     int root = -1, roots = 0;
     for (int i = 0; i < N; i++) if (!indeg[i]) { root = i; roots++; }
-    if (roots != 1) { fprintf(stderr, "_validate_edges: exactly one node should have in-degree 0\n"); goto done; }
-    for (int i = 0; i < N; i++) if (indeg[i] > 1) { fprintf(stderr, "_validate_edges: the in-degree of each node must be 0 or 1\n"); goto done; }
-    for (int i = 0; i < N; i++) if (indeg[i] + outdeg[i] < 1) { fprintf(stderr, "_validate_edges: node index %d is not an endpoint of any edge\n", i); goto done; }
+    if (roots != 1) { fprintf(stderr, "error: edges: the tree needs exactly one root (a node that is nobody's child)\n"); goto done; }
+    for (int i = 0; i < N; i++) if (indeg[i] > 1) { fprintf(stderr, "error: edges: a node has two parents\n"); goto done; }
+    for (int i = 0; i < N; i++) if (indeg[i] + outdeg[i] < 1) { fprintf(stderr, "error: edges: node %d does not occur in any edge\n", i); goto done; }
     m->N = N; m->E = E; m->root = root;
     m->indptr = malloc((N + 1) * sizeof(int));
     m->indices = malloc((E + 1) * sizeof(int));
@@ -109,12 +110,12 @@ static int parse_edges(host_model *m, const jval *edges)
         int a = m->preorder[head++];
         for (int j = m->indptr[a]; j < m->indptr[a + 1]; j++) {
             int b = m->indices[j];
-            if (visited[b]) { fprintf(stderr, "validate_edges: topo sort failed: node index %d already visited\n", b); goto done; }
+            if (visited[b]) { fprintf(stderr, "error: edges: node %d is reached twice from the root\n", b); goto done; }
             visited[b] = 1;
             m->preorder[npre++] = b;
         }
     }
-    if (npre != N) { fprintf(stderr, "validate_edges: the topo sort contains %d of the %d nodes\n", npre, N); goto done; }
+    if (npre != N) { fprintf(stderr, "error: edges: only %d of the %d nodes hang below the root\n", npre, N); goto done; }
     rc = 0;
 done:
     free(indeg); free(outdeg); free(pa); free(pb); free(fill); free(visited);
@@ -123,31 +124,31 @@ done:
 
 static int parse_rate_matrix(host_model *m, const jval *rm)
 {
-    if (!j_is_array(rm)) FAILF("_validate_rate_matrix: not an array\n");
+    if (!j_is_array(rm)) FAILF("error: rate_matrix: a square list of rows is required\n");
     const int k = (int)j_len(rm);
     m->k = k;
     m->rate_matrix = malloc((size_t)(k ? k : 1) * (k ? k : 1) * sizeof(double));
     if (!m->rate_matrix) return -1;
     for (int i = 0; i < k; i++) {
         const jval *row = j_at(rm, i);
-        if (!j_is_array(row)) FAILF("_validate_rate_matrix: this row is not an array\n");
-        if ((int)j_len(row) != k) FAILF("_validate_rate_matrix: this row length does not match the number of rows: (actual: %d desired: %d)\n", (int)j_len(row), k);
+        if (!j_is_array(row)) FAILF("error: rate_matrix: a row is not a list\n");
+        if ((int)j_len(row) != k) FAILF("error: rate_matrix: a row has %d entries, the matrix has %d rows\n", (int)j_len(row), k);
         for (int j = 0; j < k; j++) {
             const jval *y = j_at(row, j);
-            if (!j_is_number(y)) FAILF("_validate_rate_matrix: not a number\n");
+            if (!j_is_number(y)) FAILF("error: rate_matrix: an entry is not a number\n");
             double d = j_number(y);
-            if (d < 0) FAILF("_validate_rate_matrix: rate matrix entries must be nonnegative\n");
+            if (d < 0) FAILF("error: rate_matrix: negative rate (the diagonal is ignored but must not be negative either)\n");
             m->rate_matrix[(size_t)i * k + j] = d;
         }
     }
-    if (k < 1) FAILF("_validate_rate_matrix: the rate matrix is empty\n");
+    if (k < 1) FAILF("error: rate_matrix: at least one state is required\n");
     return 0;
 }
 
 static int parse_probability_array(host_model *m, const jval *pa)
 {
-    const char *name = "_validate_probability_array";
-    if (!j_is_array(pa)) FAILF("%s: expected an array\n", name);
+    const char *name = "probability_array";
+    if (!j_is_array(pa)) FAILF("error: %s: a list per site, each with one row per node, is required\n", name);
     const long S = (long)j_len(pa);
     const int N = m->N, k = m->k;
     m->S = S;
@@ -155,18 +156,19 @@ static int parse_probability_array(host_model *m, const jval *pa)
     if (!m->prob) return -1;
     for (long s = 0; s < S; s++) {
         const jval *x = j_at(pa, s);
-        if (!j_is_array(x)) FAILF("%s: expected an array\n", name);
-        if ((int)j_len(x) != N) FAILF("%s: failed to match the number of nodes: (actual: %d desired: %d)\n", name, (int)j_len(x), N);
+        if (!j_is_array(x)) FAILF("error: %s: a list per site, each with one row per node, is required\n", name);
+        if ((int)j_len(x) != N) FAILF("error: %s: a site lists %d nodes, the tree has %d\n", name, (int)j_len(x), N);
         for (int a = 0; a < N; a++)
             if (nonneg_array(m->prob + ((size_t)s * N + a) * k, k, j_at(x, a), name)) return -1;
     }
     /* Compact form ("character_data fast path"): real probability arrays consist of a handful of
      * distinct rows (one-hot states, all-ones "missing", a few ambiguity sets).  When there are at most 256 of them,
      * the array is re-expressed as character codes + definitions -- bitwise the same observation vectors -- so that
-     * the compact device layout (1 byte per node and site), the tip tables and the fused kernels apply.
-     * Opt-in (ARBPLF_COMPACT_DENSE=1) in this round: the default keeps the dense layout the parity suite was run on. */
+     * the compact device layout (1 byte per node and site), the tip tables and the fused kernels apply.  Rows are
+     * compared bit for bit (0.0 and -0.0 are different rows with the same meaning).  On by default;
+     * ARBPLF_COMPACT_DENSE=0 keeps the dense layout (and the dense generic kernels) for comparison. */
     const char *compact_env = getenv("ARBPLF_COMPACT_DENSE");
-    if (S * (long)N > 0 && compact_env && compact_env[0] == '1') {
+    if (S * (long)N > 0 && !(compact_env && compact_env[0] == '0')) {
         const size_t rows = (size_t)S * N, rb = (size_t)k * sizeof(double);
         uint8_t *codes = malloc(rows + 1);
         double *defs = malloc(256 * rb + 1);
@@ -201,10 +203,10 @@ static int parse_probability_array(host_model *m, const jval *pa)
 /* src/parsemodel.c:515-628 */
 static int parse_character_data(host_model *m, const jval *cd, const jval *defs)
 {
-    const char *name = "_validate_character_data_and_definitions";
-    if (!exists(defs)) fprintf(stderr, "%s: 'character_data' has been provided without 'character_definitions'\n", name);
-    if (!j_is_array(cd)) FAILF("%s: expected 'character_data' to be an array\n", name);
-    if (!j_is_array(defs)) FAILF("%s: expected 'character_definitions' to be an array\n", name);
+    const char *name = "character_data";
+    if (!exists(defs)) fprintf(stderr, "error: %s needs 'character_definitions' next to it\n", name);
+    if (!j_is_array(cd)) FAILF("error: %s: a list per site of one character index per node is required\n", name);
+    if (!j_is_array(defs)) FAILF("error: %s: 'character_definitions' must be a list of rows, one per character\n", name);
     const long S = (long)j_len(cd);
     const int N = m->N, k = m->k, nchar = (int)j_len(defs);
     m->S = S; m->nchar = nchar;
@@ -218,14 +220,14 @@ static int parse_character_data(host_model *m, const jval *cd, const jval *defs)
     if (!m->codes8 && !m->prob) return -1;
     for (long s = 0; s < S; s++) {
         const jval *x = j_at(cd, s);
-        if (!j_is_array(x)) FAILF("%s: expected an array\n", name);
-        if ((int)j_len(x) != N) FAILF("%s: failed to match the number of nodes: (actual: %d desired: %d)\n", name, (int)j_len(x), N);
+        if (!j_is_array(x)) FAILF("error: %s: a list per site, each with one row per node, is required\n", name);
+        if ((int)j_len(x) != N) FAILF("error: %s: a site lists %d nodes, the tree has %d\n", name, (int)j_len(x), N);
         for (int a = 0; a < N; a++) {
             const jval *y = j_at(x, a);
-            if (!j_is_int(y)) FAILF("%s: character indices must be integers\n", name);
+            if (!j_is_int(y)) FAILF("error: %s: a character index is not an integer\n", name);
             long long c = y->u.i;
-            if (c < 0) FAILF("%s: character indices must be non-negative\n", name);
-            if (c >= nchar) FAILF("%s: character indices must each be less than the character count (%d)\n", name, nchar);
+            if (c < 0) FAILF("error: %s: negative character index\n", name);
+            if (c >= nchar) FAILF("error: %s: character index beyond the %d definitions\n", name, nchar);
             if (compact) m->codes8[(size_t)s * N + a] = (uint8_t)c;
             else memcpy(m->prob + ((size_t)s * N + a) * k, m->defs + (size_t)c * k, k * sizeof(double));
         }
@@ -243,7 +245,7 @@ static int parse_character_data_file(host_model *m, const jval *path, const jval
 {
     const char *name = "character_data_file";
     if (!j_is_string(path)) FAILF("%s: expected the path of a raw byte file\n", name);
-    if (!j_is_array(defs)) FAILF("%s: expected 'character_definitions' to be an array\n", name);
+    if (!j_is_array(defs)) FAILF("error: %s: 'character_definitions' must be a list of rows, one per character\n", name);
     const int N = m->N, k = m->k, nchar = (int)j_len(defs);
     if (nchar < 1 || nchar > 256) FAILF("%s: between 1 and 256 character definitions are required\n", name);
     m->nchar = nchar;
@@ -264,14 +266,13 @@ static int parse_character_data_file(host_model *m, const jval *path, const jval
     fclose(f);
     if (got != (size_t)bytes) FAILF("%s: short read from '%s'\n", name, path->u.s);
     for (long i = 0; i < bytes; i++)
-        if (m->codes8[i] >= nchar) FAILF("%s: character indices must each be less than the character count (%d)\n", name, nchar);
+        if (m->codes8[i] >= nchar) FAILF("error: %s: character index beyond the %d definitions\n", name, nchar);
     return 0;
 }
 
 static int parse_rate_divisor(host_model *m, const jval *rd)
 {
-    const char *msg = "_validate_rate_divisor: the optional rate_divisor argument must be either a positive number "
-                      "or the string \"equilibrium_exit_rate\"\n";
+    const char *msg = "error: rate_divisor: give a number greater than zero or \"equilibrium_exit_rate\"\n";
     if (!exists(rd)) return 0;
     if (j_is_string(rd)) {
         if (strcmp(rd->u.s, "equilibrium_exit_rate")) FAILF("%s", msg);
@@ -286,8 +287,7 @@ static int parse_rate_divisor(host_model *m, const jval *rd)
 
 static int parse_root_prior(host_model *m, const jval *rp)
 {
-    const char *msg = "_validate_root_prior: the optional \"root_prior\" must be either a list of probabilities or one "
-                      "of the strings {\"equilibrium_distribution\", \"uniform_distribution\"}\n";
+    const char *msg = "error: root_prior: give one weight per state, \"equilibrium_distribution\" or \"uniform_distribution\"\n";
     if (!exists(rp)) { m->root_mode = HM_ROOT_NONE; return 0; }
     if (j_is_string(rp)) {
         if (!strcmp(rp->u.s, "equilibrium_distribution")) m->root_mode = HM_ROOT_EQUILIBRIUM;
@@ -298,7 +298,7 @@ static int parse_root_prior(host_model *m, const jval *rp)
     m->root_mode = HM_ROOT_CUSTOM;
     m->root_custom = malloc((size_t)m->k * sizeof(double));
     if (!m->root_custom) return -1;
-    if (nonneg_array(m->root_custom, m->k, rp, "_validate_root_prior")) FAILF("%s", msg);
+    if (nonneg_array(m->root_custom, m->k, rp, "root_prior")) FAILF("%s", msg);
     return 0;
 }
 
@@ -308,21 +308,21 @@ static int parse_rate_mixture(host_model *m, const jval *rm)
     static const char *const req[] = {"rates", "prior", NULL};
     if (host_check_keys(rm, req, req, "rate_mixture")) return -1;
     const jval *rates = j_get(rm, "rates"), *prior = j_get(rm, "prior");
-    if (!j_is_array(rates)) FAILF("_validate_rate_mixture: 'rates' is not an array\n");
+    if (!j_is_array(rates)) FAILF("error: rate_mixture: 'rates' must be a list of numbers\n");
     const int n = (int)j_len(rates);
-    if (n < 1) FAILF("_validate_rate_mixture: empty mixture\n");
+    if (n < 1) FAILF("error: rate_mixture: at least one category is required\n");
     m->mix_rates = malloc(n * sizeof(double));
     m->mix_prior = calloc(n, sizeof(double));
     if (!m->mix_rates || !m->mix_prior) return -1;
-    if (nonneg_array(m->mix_rates, n, rates, "_validate_rate_mixture")) FAILF("_validate_rate_mixture: invalid 'rates' array\n");
+    if (nonneg_array(m->mix_rates, n, rates, "rate_mixture")) FAILF("error: rate_mixture: 'rates' is not usable\n");
     if (j_is_string(prior)) {
         if (strcmp(prior->u.s, "uniform_distribution"))
-            FAILF("_validate_rate_mixture: the 'prior' argument must be either a nonnegative array or the string \"uniform_distribution\"\n");
+            FAILF("error: rate_mixture: 'prior' is one weight per category or \"uniform_distribution\"\n");
         m->mix.mode = K0_MIX_UNIFORM;
     } else if (j_is_array(prior)) {
-        if (nonneg_array(m->mix_prior, n, prior, "_validate_rate_mixture")) FAILF("_validate_rate_mixture: invalid 'prior' array\n");
+        if (nonneg_array(m->mix_prior, n, prior, "rate_mixture")) FAILF("error: rate_mixture: 'prior' is not usable\n");
         m->mix.mode = K0_MIX_CUSTOM;
-    } else FAILF("_validate_rate_mixture: the 'prior' argument must be either a nonnegative array or the string \"uniform_distribution\"\n");
+    } else FAILF("error: rate_mixture: 'prior' is one weight per category or \"uniform_distribution\"\n");
     m->mix.n = n; m->mix.rates = m->mix_rates; m->mix.prior = m->mix_prior;
     return 0;
 }
@@ -337,16 +337,16 @@ static int parse_gamma_mixture(host_model *m, const jval *g, int mode)
     m->mix.mode = mode;
     m->mix.invariable_prior = 0;
     if (exists(ip)) {
-        if (!j_is_number(ip)) FAILF("invariable_prior: not a number\n");
+        if (!j_is_number(ip)) FAILF("error: invariable_prior must be a number\n");
         m->mix.invariable_prior = j_number(ip);
     }
-    if (!j_is_number(gs)) FAILF("gamma_shape: not a number\n");
+    if (!j_is_number(gs)) FAILF("error: gamma_shape must be a number\n");
     m->mix.gamma_shape = j_number(gs);
-    if (!j_is_int(gc)) FAILF("gamma_categories: not an integer\n");
-    if (gc->u.i < 1 || gc->u.i > 1000000) FAILF("gamma_categories: must be a positive integer\n");
+    if (!j_is_int(gc)) FAILF("error: gamma_categories must be an integer\n");
+    if (gc->u.i < 1 || gc->u.i > 1000000) FAILF("error: gamma_categories must be at least 1\n");
     m->mix.n = (int)gc->u.i;
-    if (!(m->mix.gamma_shape > 0)) FAILF("gamma_shape: must be positive\n");
-    if (!(m->mix.invariable_prior >= 0 && m->mix.invariable_prior < 1)) FAILF("invariable_prior: must be in [0, 1)\n");
+    if (!(m->mix.gamma_shape > 0)) FAILF("error: gamma_shape must be greater than zero\n");
+    if (!(m->mix.invariable_prior >= 0 && m->mix.invariable_prior < 1)) FAILF("error: invariable_prior must lie in [0, 1)\n");
     return 0;
 }
 
@@ -362,22 +362,22 @@ int host_model_parse(host_model *m, const jval *root)
     const jval *cdata = j_get(root, "character_data"), *rmix = j_get(root, "rate_mixture");
     const jval *cfile = j_get(root, "character_data_file");
     const jval *gmix = j_get(root, "gamma_rate_mixture"), *gmed = j_get(root, "normalized_median_gamma_rate_mixture");
-    if (exists(rmix) + exists(gmix) + exists(gmed) > 1) FAILF("error: conflicting rate mixture options\n");
-    if (exists(pa) && exists(cdata)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_data' have both been specified\n");
-    if (exists(pa) && exists(cdefs)) FAILF("error: the mutually exclusive options 'probability_array' and 'character_definitions' have both been specified\n");
+    if (exists(rmix) + exists(gmix) + exists(gmed) > 1) FAILF("error: more than one of rate_mixture / gamma_rate_mixture / normalized_median_gamma_rate_mixture given\n");
+    if (exists(pa) && exists(cdata)) FAILF("error: give either 'probability_array' or 'character_data', not both\n");
+    if (exists(pa) && exists(cdefs)) FAILF("error: 'character_definitions' belongs with 'character_data', not with 'probability_array'\n");
     if (exists(cfile) && (exists(pa) || exists(cdata))) FAILF("error: 'character_data_file' excludes 'probability_array' and 'character_data'\n");
 
     if (parse_edges(m, j_get(root, "edges"))) return -1;
     m->edge_rates_user = malloc((size_t)(m->E + 1) * sizeof(double));
     m->edge_rates_csr = malloc((size_t)(m->E + 1) * sizeof(double));
     if (!m->edge_rates_user || !m->edge_rates_csr) return -1;
-    if (nonneg_array(m->edge_rates_user, m->E, j_get(root, "edge_rate_coefficients"), "_validate_edge_rate_coefficients")) return -1;
+    if (nonneg_array(m->edge_rates_user, m->E, j_get(root, "edge_rate_coefficients"), "edge_rate_coefficients")) return -1;
     for (int i = 0; i < m->E; i++) m->edge_rates_csr[m->edge_order[i]] = m->edge_rates_user[i];
     if (parse_rate_matrix(m, j_get(root, "rate_matrix"))) return -1;
     if (exists(pa)) { if (parse_probability_array(m, pa)) return -1; }
     else if (exists(cdata)) { if (parse_character_data(m, cdata, cdefs)) return -1; }
     else if (exists(cfile)) { if (parse_character_data_file(m, cfile, cdefs)) return -1; }
-    else FAILF("error: either 'probability_array' or 'character_data' must be specified\n");
+    else FAILF("error: no observations: 'probability_array' or 'character_data' is required\n");
     if (parse_rate_divisor(m, j_get(root, "rate_divisor"))) return -1;
     if (parse_root_prior(m, j_get(root, "root_prior"))) return -1;
     if (exists(gmix)) { if (parse_gamma_mixture(m, gmix, K0_MIX_GAMMA)) return -1; }
@@ -400,21 +400,21 @@ static int reduction_parse_aggregation(host_reduction *r, const char *name, cons
         if (!strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
         else if (!strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
         else if (!strcmp(agg->u.s, "only")) {
-            if (r->selection_len != 1) FAILF("error: %s aggregation (\"only\"): the selection length must be exactly 1 (selection_len = %d)\n", name, r->selection_len);
+            if (r->selection_len != 1) FAILF("error: %s_reduction: \"only\" needs a selection of exactly one index, not %d\n", name, r->selection_len);
             r->agg_mode = AGG_ONLY;
-        } else FAILF("error: %s aggregation (string): the only valid aggregation strings are {\"sum\", \"avg\", \"only\"}\n", name);
+        } else FAILF("error: %s_reduction: aggregation is \"sum\", \"avg\", \"only\" or a list of weights\n", name);
     } else if (j_is_array(agg)) {
         r->agg_mode = AGG_WEIGHTED_SUM;
-        if ((int)j_len(agg) != r->selection_len) FAILF("error: %s aggregation (weighted sum): the number of weights must be equal to the number of selected %s indices\n", name, name);
+        if ((int)j_len(agg) != r->selection_len) FAILF("error: %s_reduction: one weight per selected %s is required\n", name, name);
         r->weights = malloc((size_t)(r->selection_len + 1) * sizeof(double));
         if (!r->weights) return -1;
         for (int i = 0; i < r->selection_len; i++) {
             const jval *x = j_at(agg, i);
-            if (!j_is_number(x)) FAILF("error: %s aggregation (weighted sum): weights should be numeric\n", name);
+            if (!j_is_number(x)) FAILF("error: %s_reduction: a weight is not a number\n", name);
             r->weights[i] = j_number(x);
         }
-    } else FAILF("error: %s aggregation: if provided, the aggregation should be a string or an array of numeric weights\n", name);
-    if (r->agg_mode == AGG_AVG && r->selection_len == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
+    } else FAILF("error: %s_reduction: aggregation is neither a string nor a list of weights\n", name);
+    if (r->agg_mode == AGG_AVG && r->selection_len == 0) FAILF("error: %s_reduction: \"avg\" over nothing\n", name);
     return 0;
 }
 
@@ -435,15 +435,15 @@ int host_reduction_parse(host_reduction *r, int n, const char *name, const jval 
         if (!r->selection) return -1;
         for (int i = 0; i < n; i++) r->selection[i] = i;
     } else {
-        if (!j_is_array(sel)) FAILF("error: %s selection: the selection should be an array\n", name);
+        if (!j_is_array(sel)) FAILF("error: %s_reduction: selection must be a list\n", name);
         r->selection_len = (int)j_len(sel);
         r->selection = malloc((size_t)(r->selection_len + 1) * sizeof(int));
         if (!r->selection) return -1;
         for (int i = 0; i < r->selection_len; i++) {
             const jval *x = j_at(sel, i);
-            if (!j_is_int(x)) FAILF("error: %s selection: each index in the selection must be an integer\n", name);
-            if (x->u.i < 0) FAILF("error: %s selection: each index in the selection must be non-negative\n", name);
-            if (x->u.i >= n) FAILF("error: %s selection: each index in the selection must be less than the total number of available %s indices\n", name, name);
+            if (!j_is_int(x)) FAILF("error: %s_reduction: a selected index is not an integer\n", name);
+            if (x->u.i < 0) FAILF("error: %s_reduction: negative index in the selection\n", name);
+            if (x->u.i >= n) FAILF("error: %s_reduction: selected index beyond the last %s\n", name, name);
             r->selection[i] = (int)x->u.i;
         }
     }
@@ -467,7 +467,7 @@ int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int 
         if (j_is_null(sel)) sel = NULL;      /* _exists(): an explicit null counts as absent (:13-16) */
     }
     if (sel) {
-        if (!j_is_array(sel)) FAILF("error: %s selection: the selection should be an array\n", name);
+        if (!j_is_array(sel)) FAILF("error: %s_reduction: selection must be a list\n", name);
         const int n = (int)j_len(sel);
         r->n = n;
         r->selection_len = n;
@@ -478,10 +478,10 @@ int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int 
         for (int i = 0; i < n; i++) {
             const jval *p = j_at(sel, i);
             if (!j_is_array(p) || j_len(p) != 2 || !j_is_int(j_at(p, 0)) || !j_is_int(j_at(p, 1)))
-                FAILF("error: %s selection: each entry must be a pair of integers\n", name);
+                FAILF("error: %s_reduction: every selected entry is a pair [from, to] of integers\n", name);
             const long a = j_at(p, 0)->u.i, b = j_at(p, 1)->u.i;
             if (a < 0 || a >= k || b < 0 || b >= k)
-                FAILF("error: %s selection: indices should be nonnegative integers less than the number of column elements\n", name);
+                FAILF("error: %s_reduction: a state of a selected pair is out of range\n", name);
             (*first)[i] = (int)a; (*second)[i] = (int)b;
             r->selection[i] = i;
         }
@@ -490,7 +490,7 @@ int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int 
     if (!agg || j_is_null(agg)) r->agg_mode = AGG_NONE;
     else if (j_is_string(agg) && !strcmp(agg->u.s, "sum")) r->agg_mode = AGG_SUM;
     else if (j_is_string(agg) && !strcmp(agg->u.s, "avg")) r->agg_mode = AGG_AVG;
-    else FAILF("error: %s reduction (no selection): if no selection is specified, the only allowed aggregations are \"sum\" or \"avg\"\n", name);
+    else FAILF("error: %s_reduction: without a selection only \"sum\" and \"avg\" make sense\n", name);
     const int n = k * (k - 1);
     r->n = n;
     r->selection_len = n;
@@ -502,7 +502,7 @@ int host_pair_reduction_parse(host_reduction *r, int **first, int **second, int 
     for (int a = 0; a < k; a++)
         for (int b = 0; b < k; b++)
             if (a != b) { r->selection[i] = i; (*first)[i] = a; (*second)[i] = b; i++; }
-    if (r->agg_mode == AGG_AVG && n == 0) FAILF("error: %s aggregation (\"avg\"): empty selection\n", name);
+    if (r->agg_mode == AGG_AVG && n == 0) FAILF("error: %s_reduction: \"avg\" over nothing\n", name);
     return 0;
 }
 

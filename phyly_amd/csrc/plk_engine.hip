@@ -14,7 +14,7 @@
  * and in the included headers:
  *   plk_fused4_asm.h   k_ll_fused4_asm: the k = 4 headline kernel, interpreter in CDNA4 assembly
  *                      (src/arbplfll.c:139-170 x src/evaluate_site_lhood.c:21-57 x src/util.c:242-301)
- *   plk_fused4_asm2.h  the same with two sites per lane (option)      plk_fused4.h  the C++ variant
+ *   plk_fused4.h       the same program interpreted by a C++ loop (deeper stacks, two sites per lane option)
  *   plk_updown4.h      k_down_fused4 / k_down_store4 / k_up4: k = 4 deriv, marginal, expectations
  *                      (src/evaluate_site_forward.c:32-105, src/arbplfderiv.c:112-371,
  *                      src/arbplfmarginal.c:111-264, src/evaluate_site_frechet.c:5-42)
@@ -32,29 +32,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "plk.h"
 #include "plk_dd.h"
+#include "plk_program.h"     /* traversal program: opcodes, builder, device formats and their checkers (host only) */
 
 #define PLK_MAX_K 64
 #define PLK_MAX_C 64
-#define PLK_FUSED_SLOTS 16
-#define PLK_TILE 256
-
-/* traversal program opcodes */
-enum {
-    OP_TIP_SET = 0,   /* cur  = P_e * B_b         (b a leaf child)          */
-    OP_TIP_MUL = 1,   /* cur *= P_e * B_b                                   */
-    OP_MATVEC = 2,    /* cur  = P_e * cur         (b an internal child)     */
-    OP_PUSH = 3,      /* slot[d] = cur                                      */
-    OP_POPMUL = 4,    /* cur *= slot[d]                                     */
-    OP_NODE_MUL = 5,  /* cur *= B_a               (internal node with data) */
-    OP_SCALE = 6,     /* cur *= 2^-e, exponent accumulated (exact)          */
-    OP_END = 7
-};
-/* op.x = opcode | (tip_slot << 8); op.y = node (TIP/NODE), slot (PUSH/POP) */
 
 struct plk_engine {
     int device = 0;
@@ -89,21 +77,20 @@ struct plk_engine {
     std::vector<char> node_has_data;     /* internal nodes whose observations are not all-ones */
     double *d_w = nullptr;
 
-    /* traversal program */
+    /* traversal program (plk_program.h) */
     bool prog_dirty = true, stream_dirty = true;
-    std::vector<int2> ops;
-    std::vector<int> op_edge;            /* CSR edge per op or -1 */
-    std::vector<int> tip_edge;           /* CSR edge per tip slot */
-    std::vector<char> scale_node;        /* N: node vectors rescaled here (every >= 16 accumulated edges) */
-    std::vector<int> obs_nodes;          /* nodes whose codes the fused kernel stages */
-    int slots_needed = 0;
+    PlkProgram pg;
+    std::vector<plk_op2> &ops = pg.ops;
+    std::vector<int> &op_edge = pg.op_edge;          /* CSR edge per op or -1 */
+    std::vector<int> &tip_edge = pg.tip_edge;        /* CSR edge per tip slot */
+    std::vector<char> &scale_node = pg.scale_node;   /* N: node vectors rescaled here (every >= 16 accumulated edges) */
+    std::vector<int> &obs_nodes = pg.obs_nodes;      /* nodes whose codes the fused kernels stage */
+    int &slots_needed = pg.slots_needed;
+    PlkFused fu;                         /* fused k = 4 formats of the program */
     int2 *d_ops = nullptr;
     int4 *d_fops = nullptr;              /* fused-kernel program (C++ interpreter) */
     unsigned *d_words = nullptr;         /* fused-kernel program (assembly interpreter) */
-    bool asm_ok = false;
-    int asm_first_tip = 0, asm_first_row = 0, asm_second_row = 0;
-    std::vector<int> mat_edge;           /* CSR edge per compact matrix of the fused stream */
-    int first_row = 0;
+    std::vector<int> &mat_edge = fu.mat_edge;        /* CSR edge per compact matrix of the fused stream */
     int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr;
     double *d_PS = nullptr;              /* [C][nops][K*K] transposed: PS[j*K+i] = P[i][j] */
     double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
@@ -133,6 +120,21 @@ struct plk_engine {
 };
 
 static std::string g_create_error;
+
+/* Live engine handles.  Every entry point refuses a handle that plk_create did not return or that plk_destroy has
+ * already taken (PLK_E_ARG instead of a use after free); plk_destroy of such a handle is a no-op.  Once the process
+ * is exiting (atexit) handles are only forgotten, not torn down: the HIP runtime's own exit handlers may already
+ * have run by the time a late destructor (a garbage-collected binding object, a static of the caller) gets here. */
+static std::mutex g_live_mu;
+static std::set<const plk_engine *> g_live;
+static bool g_exiting = false, g_atexit_set = false;
+
+static bool plk_live(const plk_engine *h)
+{
+    if (!h) return false;
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return !g_exiting && g_live.count(h) != 0;
+}
 
 #define HIPCHK(h, call)                                                            \
     do {                                                                           \
@@ -353,8 +355,9 @@ __global__ void k_build_tip(int E, int ntips, int nchar, const int *__restrict__
     }
 }
 
-/* flags[n] != 0 iff some site's code at node n is not an all-ones definition */
-__global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes,
+/* flags[n] bit 0: some site's code at node n is not an all-ones definition; bit 1: some code is >= nchar
+ * (the kernels index LDS and the tip tables with the codes: an out-of-range code must never reach them) */
+__global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes, int nchar,
                              const int *__restrict__ code_trivial, int *__restrict__ flags)
 {
     /* 16 codes per lane and iteration (rows are 1024-byte padded with code 0 beyond S;
@@ -370,10 +373,11 @@ __global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ code
         for (int j = 0; j < 16; j++) {
             const long s = v * 16 + j;
             const int ch = (wds[j >> 2] >> ((j & 3) * 8)) & 0xff;
-            if (s < S) bad |= !code_trivial[ch];
+            if (s < S) bad |= ch >= nchar ? 2 : !code_trivial[ch];
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[n], 1);
+    const int wbad = (__any(bad & 1) ? 1 : 0) | (__any(bad & 2) ? 2 : 0);
+    if (wbad && (threadIdx.x & 63) == 0) atomicOr(&flags[n], wbad);
 }
 
 /* ====================================================================== */
@@ -438,7 +442,6 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
-#include "plk_fused4_asm2.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_vec.h"
@@ -965,6 +968,14 @@ extern "C" int plk_create(plk_engine **out, int device)
         delete h;
         return PLK_E_DEVICE;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!g_atexit_set) {
+            g_atexit_set = true;
+            atexit([]() { std::lock_guard<std::mutex> lk2(g_live_mu); g_exiting = true; g_live.clear(); });
+        }
+        g_live.insert(h);
+    }
     *out = h;
     return PLK_OK;
 }
@@ -972,6 +983,10 @@ extern "C" int plk_create(plk_engine **out, int device)
 extern "C" void plk_destroy(plk_engine *h)
 {
     if (!h) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (g_exiting || !g_live.erase(h)) return;
+    }
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
@@ -986,11 +1001,11 @@ extern "C" void plk_destroy(plk_engine *h)
     delete h;
 }
 
-extern "C" const char *plk_last_error(const plk_engine *h) { return h ? h->err.c_str() : "null engine"; }
+extern "C" const char *plk_last_error(const plk_engine *h) { return plk_live(h) ? h->err.c_str() : "invalid engine handle"; }
 
 extern "C" int plk_set_option(plk_engine *h, int option, long value)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (option == PLK_OPT_FORCE_GENERIC) { h->opt_force_generic = value; h->prog_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
     if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; return PLK_OK; }
@@ -1002,7 +1017,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
 
 extern "C" int plk_get_info(plk_engine *h, int what, long *out)
 {
-    if (!h || !out) return PLK_E_ARG;
+    if (!plk_live(h) || !out) return PLK_E_ARG;
     switch (what) {
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
@@ -1016,7 +1031,7 @@ extern "C" int plk_get_info(plk_engine *h, int what, long *out)
 
 extern "C" int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *indices, const int *preorder)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (N < 2 || !indptr || !indices || !preorder) { h->err = "plk_set_tree: bad arguments"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     const int E = N - 1;
@@ -1084,7 +1099,7 @@ extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, cons
                              const double *cat_rates, const double *cat_prior, int root_mode,
                              const double *root_w)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->N == 0) { h->err = "plk_set_model: set the tree first"; return PLK_E_ARG; }
     if (k < 1 || C < 1 || !Qn || !edge_rates_csr || !cat_rates || !cat_prior) { h->err = "plk_set_model: bad arguments"; return PLK_E_ARG; }
     if (k > PLK_MAX_K) { h->err = "plk_set_model: more than 64 states is not supported yet"; return PLK_E_UNSUPPORTED; }
@@ -1121,7 +1136,7 @@ extern "C" int plk_set_model(plk_engine *h, int k, int C, const double *Qn, cons
 
 extern "C" int plk_update_edge_rates(plk_engine *h, const double *edge_rates_csr)
 {
-    if (!h || !edge_rates_csr) return PLK_E_ARG;
+    if (!plk_live(h) || !edge_rates_csr) return PLK_E_ARG;
     if (h->k == 0) { h->err = "plk_update_edge_rates: set the model first"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     h->edge_rates.assign(edge_rates_csr, edge_rates_csr + h->E);
@@ -1132,7 +1147,7 @@ extern "C" int plk_update_edge_rates(plk_engine *h, const double *edge_rates_csr
 
 extern "C" int plk_get_transition_matrices(plk_engine *h, double *P_out)
 {
-    if (!h || !P_out) return PLK_E_ARG;
+    if (!plk_live(h) || !P_out) return PLK_E_ARG;
     if (h->k == 0) { h->err = "plk_get_transition_matrices: set the model first"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     if (h->model_dirty) { int rc = run_expm(h); if (rc) return rc; }
@@ -1150,7 +1165,7 @@ static int copy_in(plk_engine *h, void *dst, const void *src, size_t bytes, int 
 extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *codes, int where, int nchar,
                                       const double *defs)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->k == 0) { h->err = "plk_set_patterns_codes: set the model first"; return PLK_E_ARG; }
     if (S < 1 || !codes || nchar < 1 || nchar > 256 || !defs) { h->err = "plk_set_patterns_codes: bad arguments"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1179,21 +1194,28 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
     if ((rc = dev_alloc(h, &d_flags, (size_t)N))) { (void)hipFree(d_triv); return rc; }
     HIPCHK(h, hipMemset(d_flags, 0, N * sizeof(int)));
     hipLaunchKernelGGL(k_node_flags, dim3((unsigned)std::min<long>(64, (S + 4095) / 4096), N), dim3(256), 0, h->stream,
-                       S, Spad, h->d_codes, d_triv, d_flags);
+                       S, Spad, h->d_codes, nchar, d_triv, d_flags);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<int> flags(N);
     HIPCHK(h, hipMemcpy(flags.data(), d_flags, N * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(d_triv); (void)hipFree(d_flags);
     h->node_has_data.assign(N, 0);
-    for (int a = 0; a < N; a++) h->node_has_data[a] = flags[a] ? 1 : 0;
+    for (int a = 0; a < N; a++) {
+        if (flags[a] & 2) {
+            h->pat_mode = 0;
+            h->err = "plk_set_patterns_codes: a pattern code is not less than the number of character definitions";
+            return PLK_E_ARG;
+        }
+        h->node_has_data[a] = flags[a] ? 1 : 0;
+    }
     h->prog_dirty = true;
     return PLK_OK;
 }
 
 extern "C" int plk_set_patterns_dense(plk_engine *h, long S, const double *B, int where)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->k == 0) { h->err = "plk_set_patterns_dense: set the model first"; return PLK_E_ARG; }
     if (S < 1 || !B) { h->err = "plk_set_patterns_dense: bad arguments"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1211,7 +1233,7 @@ extern "C" int plk_set_patterns_dense(plk_engine *h, long S, const double *B, in
 
 extern "C" int plk_set_site_weights(plk_engine *h, const double *w, int where)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->pat_mode == 0) { h->err = "plk_set_site_weights: set the patterns first"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     if (!w) { if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; } return PLK_OK; }
@@ -1226,102 +1248,21 @@ extern "C" int plk_set_site_weights(plk_engine *h, const double *w, int where)
 
 static int build_program(plk_engine *h)
 {
-    const int N = h->N;
-    const std::vector<int> &ip = h->indptr, &ix = h->indices;
-    std::vector<int> need(N, 0), since(N, 0);
-    std::vector<char> &scale_here = h->scale_node;
-    scale_here.assign(N, 0);
-    std::vector<std::vector<int>> ichild(N); /* internal children (CSR edge idx), sorted by need desc */
-    for (int u = N - 1; u >= 0; u--) {
-        const int a = h->preorder[u];
-        if (ip[a + 1] == ip[a]) continue;
-        std::vector<int> &ic = ichild[a];
-        int acc = 0;
-        for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
-            const int b = ix[idx];
-            acc += since[b] + 1;
-            if (ip[b + 1] > ip[b]) ic.push_back(idx);
-        }
-        std::stable_sort(ic.begin(), ic.end(), [&](int x, int y) { return need[ix[x]] > need[ix[y]]; });
-        int nd = 0;
-        for (size_t i = 0; i < ic.size(); i++) nd = std::max(nd, need[ix[ic[i]]] + (i > 0 ? 1 : 0));
-        need[a] = nd;
-        if (acc >= 16) { scale_here[a] = 1; acc = 0; }
-        since[a] = acc;
-    }
-    const int root = h->preorder[0];
-    h->slots_needed = need[root];
-
-    h->ops.clear(); h->op_edge.clear(); h->tip_edge.clear(); h->obs_nodes.clear();
-    std::vector<int> obs_row(N, -1);
-    auto obs = [&](int node) {
-        if (obs_row[node] < 0) { obs_row[node] = (int)h->obs_nodes.size(); h->obs_nodes.push_back(node); }
-        return obs_row[node];
-    };
-    auto emit = [&](int code, int tslot, int arg, int edge) {
-        int2 o; o.x = code | (tslot << 8); o.y = arg;
-        h->ops.push_back(o); h->op_edge.push_back(edge);
-    };
-    /* iterative post-order emission; frame = (node, depth, stage) */
-    struct Frame { int a, depth, stage; bool started; };
-    std::vector<Frame> stk;
-    stk.push_back({root, 0, 0, false});
-    while (!stk.empty()) {
-        Frame &f = stk.back();
-        const int a = f.a;
-        const std::vector<int> &ic = ichild[a];
-        if (f.stage == 0) {
-            f.stage = 1;
-            if (!ic.empty()) { stk.push_back({ix[ic[0]], f.depth, 0, false}); continue; }
-        }
-        if (f.stage == 1) {
-            if (!ic.empty()) { emit(OP_MATVEC, 0, 0, ic[0]); f.started = true; }
-            for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
-                const int b = ix[idx];
-                if (ip[b + 1] > ip[b]) continue;
-                const int t = (int)h->tip_edge.size();
-                h->tip_edge.push_back(idx);
-                /* fused kernel reads codes through staged rows; generic reads the node directly */
-                emit(f.started ? OP_TIP_MUL : OP_TIP_SET, t, b, idx);
-                obs(b);
-                f.started = true;
-            }
-            f.stage = 2;
-        }
-        if (f.stage >= 2) {
-            const int i = f.stage - 1; /* next internal child index (>= 1) */
-            if (f.stage > 2) { /* returning from child i-1 */
-                emit(OP_MATVEC, 0, 0, ic[i - 1]);
-                emit(OP_POPMUL, 0, f.depth, -1);
-            }
-            if (i < (int)ic.size()) {
-                emit(OP_PUSH, 0, f.depth, -1);
-                f.stage++;
-                const int child = ix[ic[i]];
-                const int depth = f.depth + 1;
-                stk.push_back({child, depth, 0, false});
-                continue;
-            }
-            if (h->node_has_data[a]) { emit(OP_NODE_MUL, 0, a, -1); obs(a); }
-            if (scale_here[a]) emit(OP_SCALE, 0, a, -1);   /* y = the node (used by the storing down pass) */
-            stk.pop_back();
-        }
-    }
+    if (h->node_has_data.size() != (size_t)h->N) h->node_has_data.assign(h->N, 1);
+    plk_program_build(h->N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), h->pg);
+    const std::string bad = plk_program_check(h->N, h->indptr.data(), h->indices.data(), h->preorder.data(),
+                                              h->node_has_data.data(), h->pg);
+    if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     h->prog_dirty = false;
     h->stream_dirty = true;
     return PLK_OK;
 }
 
-/* sites per lane of the fused kernel: 2 when the AGPR stack (<= 8 slots) and LDS allow it */
+/* sites per lane of the fused kernel: 1 (the assembly interpreter, the fastest variant measured) unless the
+ * option asks for the two-sites C++ variant and the stack (<= 8 slots) allows it */
 static int fused_sites_per_lane(const plk_engine *h)
 {
-    if (h->opt_fused_ns == 1 || h->opt_fused_ns == 2) {
-        if (h->opt_fused_ns == 2 && h->slots_needed > 8) return 1;
-        return (int)h->opt_fused_ns;
-    }
-    const size_t lds2 = (size_t)h->tip_edge.size() * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE * 2;
-    (void)lds2;
-    return 1;   /* the assembly interpreter (one site per lane) is the fastest variant measured */
+    return h->opt_fused_ns == 2 && h->slots_needed <= 8 ? 2 : 1;
 }
 
 /* register-resident vector kernel (plk_vec.h): 9 <= k <= 32 with compact codes (amino acids); PLK_OPT_MFMA = 2
@@ -1337,13 +1278,19 @@ static bool use_mfma(const plk_engine *h)
     return !h->opt_force_generic && h->opt_mfma && h->pat_mode == 1 && h->k >= 9 && h->k <= 64;
 }
 
+/* dynamic LDS of k_ll_mfma: the A fragments of one matrix + one 64-byte code row per observed node */
+static size_t mfma_ll_lds_bytes(const plk_engine *h)
+{
+    const int T = (h->k + 15) / 16, kk4 = (h->k + 3) / 4;
+    return (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)64;
+}
+
 static bool use_fused(const plk_engine *h)
 {
     if (h->opt_force_generic) return false;
     if (h->k != 4 || h->pat_mode != 1) return false;
     if (h->slots_needed > PLK_FUSED_SLOTS) return false;
-    const size_t lds = (size_t)(h->tip_edge.size() + 1) * h->nchar * 4 * sizeof(double) + h->obs_nodes.size() * PLK_TILE;
-    return lds <= 150 * 1024;
+    return plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * fused_sites_per_lane(h)) <= PLK_LDS_LIMIT;
 }
 
 /* upload the program and (re)build the matrix stream / tip tables */
@@ -1354,27 +1301,10 @@ static int prepare_stream(plk_engine *h, bool fused)
     const int K = h->K, C = h->C;
     if (fused) {
         if (!h->d_fops || h->stream_dirty) {
-            /* fused format: int4 {opcode|tip<<8, row/slot, next observation row, matrix index},
-             * compact matrix list, one trailing OP_END for the one-op-ahead fetch */
-            std::vector<int> row(h->N, -1);
-            for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-            const int npad = ((nops + 1) / 2) * 2 + 2;   /* even count + one spare pair for the look-ahead */
-            std::vector<int4> fops(npad);
-            h->mat_edge.clear();
-            int next_row = 0;
-            for (int pc = nops - 1; pc >= 0; pc--) {
-                const int2 o = h->ops[pc];
-                const int code = o.x & 0xff;
-                int4 f; f.x = o.x; f.y = o.y; f.z = next_row; f.w = 0;
-                if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) { f.y = row[o.y]; next_row = f.y; }
-                fops[pc] = f;
-            }
-            h->first_row = next_row;
-            for (int pc = 0; pc < nops; pc++)
-                if ((fops[pc].x & 0xff) == OP_MATVEC) { fops[pc].w = (int)h->mat_edge.size(); h->mat_edge.push_back(h->op_edge[pc]); }
-            int4 endop; endop.x = OP_END; endop.y = endop.z = endop.w = 0;
-            for (int pc = nops; pc < npad; pc++) fops[pc] = endop;
-            if ((rc = dev_upload(h, &h->d_fops, fops.data(), fops.size()))) return rc;
+            /* device formats of the program: int4 ops of the C++ interpreter, 32-bit op words of the assembly
+             * interpreter, compact matrix list (plk_program.h) */
+            plk_fused_build(h->N, h->pg, h->fu);
+            if ((rc = dev_upload(h, &h->d_fops, reinterpret_cast<const int4 *>(h->fu.fops.data()), h->fu.fops.size()))) return rc;
             {
                 std::vector<int> me = h->mat_edge;
                 me.push_back(-1);                        /* the spare matrix is all zeros */
@@ -1388,44 +1318,7 @@ static int prepare_stream(plk_engine *h, bool fused)
                 if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
             }
             if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
-            /* assembly interpreter: 32-bit op words {opcode | y<<3 | z<<16} in blocks of 8; an
-             * observation op carries the tip slot of the NEXT observation op (y) and the code
-             * row of the one after next (z): the prefetch chain of plk_fused4_asm.h */
-            {
-                const int ntips = (int)h->tip_edge.size();
-                std::vector<int> obs_pc, obs_t, obs_row;
-                for (int pc = 0; pc < nops; pc++) {
-                    const int code = fops[pc].x & 0xff;
-                    if (code == OP_TIP_SET || code == OP_TIP_MUL) { obs_pc.push_back(pc); obs_t.push_back(fops[pc].x >> 8); obs_row.push_back(fops[pc].y); }
-                    else if (code == OP_NODE_MUL) { obs_pc.push_back(pc); obs_t.push_back(ntips); obs_row.push_back(fops[pc].y); }
-                }
-                const int nwords = ((nops + 1 + 7) / 8) * 8 + 8;
-                std::vector<unsigned> words(nwords, (unsigned)OP_END);
-                size_t oi = 0;
-                bool matvec_since_obs = false;   /* a MATVEC (full wait) ran since the last observation op */
-                for (int pc = 0; pc < nops; pc++) {
-                    const int code = fops[pc].x & 0xff;
-                    unsigned wv = (unsigned)code;
-                    if (code == OP_MATVEC) matvec_since_obs = true;
-                    if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                        const unsigned tn = oi + 1 < obs_t.size() ? (unsigned)obs_t[oi + 1] : 0u;
-                        const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
-                        /* opcode 5 in the word format = TIP_MUL that may skip its wait (plk_fused4_asm.h) */
-                        unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET : (matvec_since_obs && oi > 0 ? 5u : (unsigned)OP_TIP_MUL);
-                        wv = oc | (tn << 3) | (rn << 16);
-                        matvec_since_obs = false;
-                        oi++;
-                    } else if (code == OP_PUSH || code == OP_POPMUL) {
-                        wv |= (unsigned)fops[pc].y << 3;
-                    }
-                    words[pc] = wv;
-                }
-                h->asm_first_tip = obs_t.empty() ? 0 : obs_t[0];
-                h->asm_first_row = obs_row.empty() ? 0 : obs_row[0];
-                h->asm_second_row = obs_row.size() > 1 ? obs_row[1] : 0;
-                h->asm_ok = h->slots_needed <= 8 && ntips + 1 < 8192 && h->obs_nodes.size() < 65536;
-                if ((rc = dev_upload(h, &h->d_words, words.data(), words.size()))) return rc;
-            }
+            if ((rc = dev_upload(h, &h->d_words, h->fu.words.data(), h->fu.words.size()))) return rc;
         }
         const int nmat = (int)h->mat_edge.size();
         /* one spare matrix per category: the kernel always keeps the next matrix of the stream loaded */
@@ -1442,7 +1335,7 @@ static int prepare_stream(plk_engine *h, bool fused)
         if (!h->d_ops || h->stream_dirty) {
             /* OP_MATVEC ops name the next OP_MATVEC (y, wrapping to the first): the vector kernel touches the
              * cache lines of the next matrix while it multiplies with the current one */
-            std::vector<int2> gops(h->ops);
+            std::vector<plk_op2> gops(h->ops);
             int first = -1, prev = -1;
             for (int pc = 0; pc < nops; pc++)
                 if ((gops[pc].x & 0xff) == OP_MATVEC) {
@@ -1451,7 +1344,7 @@ static int prepare_stream(plk_engine *h, bool fused)
                     prev = pc;
                 }
             if (prev >= 0) gops[prev].y = first;
-            if ((rc = dev_upload(h, &h->d_ops, gops.data(), gops.size()))) return rc;
+            if ((rc = dev_upload(h, &h->d_ops, reinterpret_cast<const int2 *>(gops.data()), gops.size()))) return rc;
             if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
         }
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;
@@ -1477,7 +1370,7 @@ static void launch_generic(plk_engine *h, const GenArgs &a, unsigned grid)
 
 extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_ll: tree, model and patterns must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
@@ -1485,7 +1378,9 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
     const bool fused = use_fused(h);
-    const long kind = fused ? 1 : (use_vec(h) ? 4 : (use_mfma(h) ? 3 : 2));
+    /* trees with so many observed nodes that their staged code rows do not fit in LDS take the generic kernel */
+    const bool vec = !fused && use_vec(h), mfma = !fused && !vec && use_mfma(h) && mfma_ll_lds_bytes(h) <= PLK_LDS_LIMIT;
+    const long kind = fused ? 1 : (vec ? 4 : (mfma ? 3 : 2));
     if (h->stream_dirty || kind != h->info_ll_kernel) {
         h->stream_dirty = true;
         h->mfma_dirty = true;
@@ -1506,38 +1401,39 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         FusedArgs a;
         a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size(); a.nmat = (int)h->mat_edge.size();
         a.ntips = (int)h->tip_edge.size() + 1; a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
-        a.root_mode = h->root_mode; a.first_row = h->first_row; a.ops = h->d_fops; a.PS = h->d_PS; a.tip = h->d_tip;
+        a.ops = h->d_fops; a.PS = h->d_PS; a.tip = h->d_tip;
         a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
         a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
-        const size_t lds = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * PLK_TILE * NS;
-        if (NS == 1 && h->asm_ok && h->opt_fused_asm) {
+        a.root_mode = h->root_mode; a.first_row = h->fu.first_row;
+        const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
+        const bool use_asm = NS == 1 && h->fu.asm_ok && h->opt_fused_asm;
+        const int D = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : 16);
+        if (use_asm) {
             FusedAsmArgs aa;
             aa.f = a; aa.words = h->d_words;
-            aa.first_tip = h->asm_first_tip; aa.first_row = h->asm_first_row; aa.second_row = h->asm_second_row;
+            aa.first_tip = h->fu.asm_first_tip; aa.first_row = h->fu.asm_first_row; aa.second_row = h->fu.asm_second_row;
             aa.pack4 = h->nchar <= 16 ? 1 : 0;
-            const size_t lds_asm = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * (aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
-            if (h->slots_needed <= 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            const size_t lds_asm = plk_fused_lds_bytes(h->pg, h->nchar, aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
+            /* replay the interpreter's fetches and LDS addresses on the host before launching (plk_program.h) */
+            const std::string bad = plk_fused_check_asm(h->N, h->pg, h->fu, h->nchar, D, aa.pack4, lds_asm);
+            if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+            if (D == 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
             else hipLaunchKernelGGL(k_ll_fused4_asm<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-        } else if (NS == 2 && h->asm_ok && h->opt_fused_asm) {
-            /* two sites per lane in the assembly interpreter: 512-site tiles */
-            FusedAsmArgs aa;
-            aa.f = a; aa.words = h->d_words;
-            aa.first_tip = h->asm_first_tip; aa.first_row = h->asm_first_row; aa.second_row = h->asm_second_row;
-            aa.pack4 = h->nchar <= 16 ? 1 : 0;
-            const size_t lds_asm = (size_t)a.ntips * a.nchar * 4 * sizeof(double) + (size_t)a.nobs * (aa.pack4 ? PLK_TILE : 2 * PLK_TILE);
-            if (h->slots_needed <= 4) hipLaunchKernelGGL(k_ll_fused4_asm2<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-            else hipLaunchKernelGGL(k_ll_fused4_asm2<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-        } else if (NS == 2) {
-            if (h->slots_needed <= 4) launch_fused<4, 2>(h, a, grid, lds);
-            else launch_fused<8, 2>(h, a, grid, lds);
         } else {
-            if (h->slots_needed <= 4) launch_fused<4, 1>(h, a, grid, lds);
-            else if (h->slots_needed <= 8) launch_fused<8, 1>(h, a, grid, lds);
-            else launch_fused<16, 1>(h, a, grid, lds);
+            const std::string bad = plk_fused_check_cpp(h->N, h->pg, h->fu, h->nchar, NS == 2 && D == 16 ? 8 : D, NS, lds);
+            if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+            if (NS == 2) {
+                if (D == 4) launch_fused<4, 2>(h, a, grid, lds);
+                else launch_fused<8, 2>(h, a, grid, lds);
+            } else {
+                if (D == 4) launch_fused<4, 1>(h, a, grid, lds);
+                else if (D == 8) launch_fused<8, 1>(h, a, grid, lds);
+                else launch_fused<16, 1>(h, a, grid, lds);
+            }
         }
         h->info_ll_kernel = 1;
-    } else if (use_vec(h)) {
+    } else if (vec) {
         /* 9 <= k <= 32 with compact codes: register-resident vector kernel (plk_vec.h) */
         const int K = h->K, nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
         grid = (unsigned)((S + VEC_BLOCK - 1) / VEC_BLOCK);
@@ -1564,7 +1460,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         else if (K == 20) hipLaunchKernelGGL(k_ll_vec<20>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         else hipLaunchKernelGGL(k_ll_vec<32>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         h->info_ll_kernel = 4;
-    } else if (use_mfma(h)) {
+    } else if (mfma) {
         /* 9 <= k <= 64 with compact codes: fp64 matrix-core kernel (plk_mfma.h) */
         const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
         const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
@@ -1583,25 +1479,13 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
             if ((rc = dev_reserve(h, &h->d_frag, &h->frag_cap, (size_t)h->C * nops * T * kk4 * 64))) return rc;
             if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4 * R))) return rc;
             {   /* MFMA program: observation ops name their staged code row and the next observation op */
-                std::vector<int> row(h->N, -1);
-                for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-                std::vector<int4> mops(nops);
-                int first = -1, prev = -1;
-                for (int pc = 0; pc < nops; pc++) {
-                    const int code = h->ops[pc].x & 0xff;
-                    int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
-                    if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                        const int slot = code == OP_NODE_MUL ? ntips : (o.x >> 8);
-                        o.y = row[h->ops[pc].y];
-                        if (first < 0) { first = pc; h->mfma_first_slot = slot; h->mfma_first_row = o.y; }
-                        if (prev >= 0) { mops[prev].z = slot; mops[prev].w = o.y; }
-                        prev = pc;
-                    }
-                    mops[pc] = o;
-                }
-                if (prev >= 0) { mops[prev].z = h->mfma_first_slot | (1 << 30); mops[prev].w = h->mfma_first_row; }
-                else h->mfma_first_slot = -1;
-                if ((rc = dev_upload(h, &h->d_mops, mops.data(), mops.size()))) return rc;
+                PlkChain ch;
+                plk_chain_build(h->N, h->pg, 0, nullptr, nullptr, nullptr, nullptr, ch);
+                const std::string bad = plk_chain_check(h->N, h->pg, ch, 0, INT_MAX, 0, 0, 0, MF_SITES,
+                                                        (size_t)h->obs_nodes.size() * MF_SITES);
+                if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+                h->mfma_first_slot = ch.first_slot; h->mfma_first_row = ch.first_row;
+                if ((rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(ch.ops.data()), ch.ops.size()))) return rc;
                 if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
             }
             hipLaunchKernelGGL(k_build_frag, dim3(nops, h->C), dim3(256), 0, h->stream,
@@ -1620,7 +1504,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
         a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
         a.partial = sum_out ? h->d_partial + 4 : nullptr;
-        const size_t lds = (size_t)T * kk4 * 64 * sizeof(double) + (size_t)a.nobs * MF_SITES;
+        const size_t lds = mfma_ll_lds_bytes(h);
         if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 3) hipLaunchKernelGGL(k_ll_mfma_occ4<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
@@ -1739,19 +1623,13 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     int *d_has = nullptr, *d_ns = nullptr, *d_obsm = nullptr;
     int4 *d_dops = nullptr;
     /* program of the depth-first down pass (k_down_fused_mfma) */
-    std::vector<int4> dops(h->ops.size());
+    PlkChain dch;
+    plk_chain_build(N, h->pg, 2, h->indices.data(), node_int.data(), edge_int.data(), node_scale.data(), dch);
     {
-        std::vector<int> row(N, -1);
-        for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-        for (size_t pc = 0; pc < h->ops.size(); pc++) {
-            const int code = h->ops[pc].x & 0xff;
-            int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
-            if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) o.y = row[h->ops[pc].y];
-            else if (code == OP_MATVEC) { o.y = h->op_edge[pc]; o.z = node_int[h->indices[o.y]]; o.w = edge_int[o.y]; }
-            else if (code == OP_SCALE) o.y = node_scale[h->ops[pc].y];
-            dops[pc] = o;
-        }
+        const std::string bad = plk_chain_check(N, h->pg, dch, 2, INT_MAX, nin, nie, nsc, MF_SITES, (size_t)h->obs_nodes.size() * MF_SITES);
+        if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
+    const std::vector<plk_op4> &dops = dch.ops;
     const int nslots_m = std::max(h->slots_needed, 1);
     double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
     auto cleanup = [&]() {
@@ -1762,7 +1640,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)E)) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)E)) ||
         (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
         (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) || (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
-        (rc = dev_upload(h, &d_dops, dops.data(), dops.size())) || (rc = dev_upload(h, &d_obsm, h->obs_nodes.data(), h->obs_nodes.size())) ||
+        (rc = dev_upload(h, &d_dops, reinterpret_cast<const int4 *>(dops.data()), dops.size())) || (rc = dev_upload(h, &d_obsm, h->obs_nodes.data(), h->obs_nodes.size())) ||
         (rc = dev_alloc(h, &d_fP, nfr)) || (rc = dev_alloc(h, &d_fPT, nfr)) || (rc = dev_alloc(h, &d_fD, nfr)) ||
         (rc = dev_alloc(h, &d_tipd, ntab)) || (rc = dev_alloc(h, &d_dtip, ntab))) { cleanup(); return rc; }
     if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
@@ -1809,7 +1687,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         a.FN = p; p += (size_t)nin * C * R * a.stride;
         a.node_scale = d_ns;
         MDownProg pg;
-        pg.ops = d_dops; pg.nops = (int)dops.size(); pg.nobs = (int)h->obs_nodes.size(); pg.obs_nodes = d_obsm;
+        pg.ops = d_dops; pg.nops = (int)h->ops.size(); pg.nobs = (int)h->obs_nodes.size(); pg.obs_nodes = d_obsm;
         pg.slots = p; p += (size_t)nslots_m * R * a.stride;
         a.SC = p; p += (size_t)nsc * C * n;
         a.CW = p; p += (size_t)C * n;
@@ -1895,33 +1773,16 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         }
     }
     /* down-pass program: observation ops carry their staged code row and the (slot, row) of the next one */
-    std::vector<int4> ops2(h->ops.size() + 1);
-    { int4 e4; e4.x = OP_END; e4.y = e4.z = e4.w = 0; ops2.back() = e4; }      /* read one op ahead */
-    int first_slot2 = -1, first_row2 = 0;
+    PlkChain ch2;
+    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch2);
     const int nobs2 = (int)h->obs_nodes.size();
     {
-        std::vector<int> row(N, -1);
-        for (size_t r = 0; r < h->obs_nodes.size(); r++) row[h->obs_nodes[r]] = (int)r;
-        int prev = -1;
-        for (size_t pc = 0; pc < h->ops.size(); pc++) {
-            const int code = h->ops[pc].x & 0xff;
-            int4 o; o.x = h->ops[pc].x; o.y = h->ops[pc].y; o.z = 0; o.w = 0;
-            if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                const int slot = code == OP_NODE_MUL ? ntips : (o.x >> 8);
-                o.y = row[h->ops[pc].y];
-                if (prev < 0) { first_slot2 = slot; first_row2 = o.y; }
-                else { ops2[prev].z = slot; ops2[prev].w = o.y; }
-                prev = (int)pc;
-            } else if (code == OP_MATVEC) {
-                o.y = h->op_edge[pc];
-                o.z = node_int[h->indices[h->op_edge[pc]]];
-            } else if (code == OP_SCALE) {
-                o.y = node_scale[h->ops[pc].y];
-            }
-            ops2[pc] = o;
-        }
-        if (prev >= 0) { ops2[prev].z = first_slot2 | (1 << 30); ops2[prev].w = first_row2; }
+        const int D2 = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : (h->slots_needed <= 16 ? 16 : INT_MAX));
+        const std::string bad = plk_chain_check(N, h->pg, ch2, 1, D2, nin, nie, nsc, UD4_BLOCK, (size_t)nobs2 * UD4_BLOCK);
+        if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
+    const std::vector<plk_op4> &ops2 = ch2.ops;
+    const int first_slot2 = ch2.first_slot, first_row2 = ch2.first_row;
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
@@ -2163,7 +2024,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
 
 extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_out, double *edge_sums_out)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     return run_updown(h, true, false, edge_mask, nullptr, site_edge_out, edge_sums_out);
 }
 
@@ -2173,7 +2034,7 @@ extern "C" int plk_deriv(plk_engine *h, const int *edge_mask, double *site_edge_
 extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, const double *L_lo, int coef_mode,
                                      const int *edge_mask, double *site_out, double *sums_out)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_edge_expect: tree, model and patterns must be set"; return PLK_E_ARG; }
     if (!L_hi || nL < 1 || coef_mode < PLK_COEF_PRIOR || coef_mode > PLK_COEF_PRIOR_RATE) { h->err = "plk_edge_expect: bad direction matrix or coefficient mode"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -2245,7 +2106,7 @@ extern "C" int plk_edge_expect(plk_engine *h, const double *L_hi, const double *
 
 extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const double *L_lo, int coef_mode, double *F_out)
 {
-    if (!h || !L_hi || !F_out) return PLK_E_ARG;
+    if (!plk_live(h) || !L_hi || !F_out) return PLK_E_ARG;
     if (h->k == 0) { h->err = "plk_get_frechet_matrices: model must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
@@ -2280,7 +2141,7 @@ extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const
 
 extern "C" int plk_marginal(plk_engine *h, const int *node_mask, double *site_out, double *sums_out)
 {
-    if (!h) return PLK_E_ARG;
+    if (!plk_live(h)) return PLK_E_ARG;
     return run_updown(h, false, true, nullptr, node_mask, site_out, sums_out);
 }
 
@@ -2310,7 +2171,7 @@ static int fit_objective(plk_engine *h, const std::vector<double> &rates, long d
 extern "C" int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, double ftol, const int *edge_mask,
                                   double *rates_inout, double *ll_trace, int *iters_out, long *evals_out)
 {
-    if (!h || !rates_inout) return PLK_E_ARG;
+    if (!plk_live(h) || !rates_inout) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_fit_edge_rates: tree, model and patterns must be set"; return PLK_E_ARG; }
     if (method != PLK_FIT_EM && method != PLK_FIT_LBFGS) { h->err = "plk_fit_edge_rates: unknown method"; return PLK_E_ARG; }
     const int E = h->E, k = h->k;
@@ -2515,7 +2376,7 @@ static void launch_hess_pass_k(plk_engine *h, const UpArgs &a, unsigned grid)
  */
 extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
 {
-    if (!h || !hess_sums_out) return PLK_E_ARG;
+    if (!plk_live(h) || !hess_sums_out) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_hess: tree, model and patterns must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;

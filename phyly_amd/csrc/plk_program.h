@@ -1,0 +1,508 @@
+/*
+ * plk_program.h -- the traversal program of the pruning kernels: builder, device formats and checkers.
+ * Host-only C++ (no HIP types), included by plk_engine.hip and by the CPU test driver tests/progcheck_main.cpp.
+ *
+ * The reference walks the tree with pointers per site (src/evaluate_site_lhood.c:21-57 over the preorder of
+ * src/model.h:62-67).  Here the walk is compiled once per query into a wave-uniform post-order *program* that the
+ * kernels interpret for every site; the formats derived from it are what the device code indexes LDS, the matrix
+ * stream, the tip tables and the register stack with.  Everything the device will dereference is therefore
+ * decided on the host, and the plk_check_* functions below replay the interpreters' address arithmetic on the
+ * host (same field widths, same look-ahead fetches) so that a program that would step outside a buffer is
+ * refused with PLK_E_ARG before any launch.
+ */
+#ifndef PLK_PROGRAM_H
+#define PLK_PROGRAM_H
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+/* traversal program opcodes */
+enum {
+    OP_TIP_SET = 0,   /* cur  = P_e * B_b         (b a leaf child)          */
+    OP_TIP_MUL = 1,   /* cur *= P_e * B_b                                   */
+    OP_MATVEC = 2,    /* cur  = P_e * cur         (b an internal child)     */
+    OP_PUSH = 3,      /* slot[d] = cur                                      */
+    OP_POPMUL = 4,    /* cur *= slot[d]                                     */
+    OP_NODE_MUL = 5,  /* cur *= B_a               (internal node with data) */
+    OP_SCALE = 6,     /* cur *= 2^-e, exponent accumulated (exact)          */
+    OP_END = 7
+};
+/* opcode 5 of the assembly interpreter's word format: TIP_MUL that may skip its wait (plk_fused4_asm.h) */
+#define PLK_WORD_TIPMUL_NOWAIT 5u
+
+struct plk_op2 { int x, y; };          /* layout of HIP's int2: x = opcode | tip_slot << 8, y = node / stack slot */
+struct plk_op4 { int x, y, z, w; };    /* layout of HIP's int4 */
+
+#define PLK_TILE 256                   /* sites per workgroup of the fused k = 4 kernels */
+#define PLK_FUSED_SLOTS 16             /* deepest register stack any fused kernel is compiled for */
+#define PLK_LDS_LIMIT (150 * 1024)     /* dynamic LDS the fused kernels may ask for (160 KB per CU on gfx950) */
+
+struct PlkProgram {
+    std::vector<plk_op2> ops;
+    std::vector<int> op_edge;          /* CSR edge per op or -1 */
+    std::vector<int> tip_edge;         /* CSR edge per tip slot */
+    std::vector<char> scale_node;      /* N: node vectors rescaled here (every >= 16 accumulated edges) */
+    std::vector<int> obs_nodes;        /* nodes whose code rows the fused kernels stage, in order of first use */
+    int slots_needed = 0;              /* Sethi-Ullman number of the tree = depth of the waiting-vector stack */
+};
+
+/*
+ * Post-order program of a rooted tree in CSR form (preorder[0] = root, parents first).  Internal children are
+ * visited in order of decreasing stack need, so the stack depth is the tree's Sethi-Ullman number (<= log2 of the
+ * leaf count for binary trees).  node_has_data[a] != 0 for internal nodes whose observation row is not all ones.
+ */
+static inline void plk_program_build(int N, const int *ip, const int *ix, const int *preorder,
+                                     const char *node_has_data, PlkProgram &pg)
+{
+    std::vector<int> need(N, 0), since(N, 0);
+    pg.scale_node.assign(N, 0);
+    std::vector<std::vector<int>> ichild(N); /* internal children (CSR edge idx), sorted by need desc */
+    for (int u = N - 1; u >= 0; u--) {
+        const int a = preorder[u];
+        if (ip[a + 1] == ip[a]) continue;
+        std::vector<int> &ic = ichild[a];
+        int acc = 0;
+        for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
+            const int b = ix[idx];
+            acc += since[b] + 1;
+            if (ip[b + 1] > ip[b]) ic.push_back(idx);
+        }
+        std::stable_sort(ic.begin(), ic.end(), [&](int x, int y) { return need[ix[x]] > need[ix[y]]; });
+        int nd = 0;
+        for (size_t i = 0; i < ic.size(); i++) nd = std::max(nd, need[ix[ic[i]]] + (i > 0 ? 1 : 0));
+        need[a] = nd;
+        if (acc >= 16) { pg.scale_node[a] = 1; acc = 0; }
+        since[a] = acc;
+    }
+    const int root = preorder[0];
+    pg.slots_needed = need[root];
+
+    pg.ops.clear(); pg.op_edge.clear(); pg.tip_edge.clear(); pg.obs_nodes.clear();
+    std::vector<int> obs_row(N, -1);
+    auto obs = [&](int node) {
+        if (obs_row[node] < 0) { obs_row[node] = (int)pg.obs_nodes.size(); pg.obs_nodes.push_back(node); }
+        return obs_row[node];
+    };
+    auto emit = [&](int code, int tslot, int arg, int edge) {
+        plk_op2 o; o.x = code | (tslot << 8); o.y = arg;
+        pg.ops.push_back(o); pg.op_edge.push_back(edge);
+    };
+    /* iterative post-order emission; frame = (node, depth, stage) */
+    struct Frame { int a, depth, stage; bool started; };
+    std::vector<Frame> stk;
+    stk.push_back({root, 0, 0, false});
+    while (!stk.empty()) {
+        Frame &f = stk.back();
+        const int a = f.a;
+        const std::vector<int> &ic = ichild[a];
+        if (f.stage == 0) {
+            f.stage = 1;
+            if (!ic.empty()) { const Frame nf = {ix[ic[0]], f.depth, 0, false}; stk.push_back(nf); continue; }
+        }
+        if (f.stage == 1) {
+            if (!ic.empty()) { emit(OP_MATVEC, 0, 0, ic[0]); f.started = true; }
+            for (int idx = ip[a]; idx < ip[a + 1]; idx++) {
+                const int b = ix[idx];
+                if (ip[b + 1] > ip[b]) continue;
+                const int t = (int)pg.tip_edge.size();
+                pg.tip_edge.push_back(idx);
+                emit(f.started ? OP_TIP_MUL : OP_TIP_SET, t, b, idx);
+                obs(b);
+                f.started = true;
+            }
+            f.stage = 2;
+        }
+        if (f.stage >= 2) {
+            const int i = f.stage - 1; /* next internal child index (>= 1) */
+            if (f.stage > 2) { /* returning from child i-1 */
+                emit(OP_MATVEC, 0, 0, ic[i - 1]);
+                emit(OP_POPMUL, 0, f.depth, -1);
+            }
+            if (i < (int)ic.size()) {
+                emit(OP_PUSH, 0, f.depth, -1);
+                f.stage++;
+                const Frame nf = {ix[ic[i]], f.depth + 1, 0, false};
+                stk.push_back(nf);      /* invalidates f */
+                continue;
+            }
+            if (node_has_data[a]) { emit(OP_NODE_MUL, 0, a, -1); obs(a); }
+            if (pg.scale_node[a]) emit(OP_SCALE, 0, a, -1);   /* y = the node (used by the storing down pass) */
+            stk.pop_back();
+        }
+    }
+}
+
+static inline std::string plk_fmt(const char *fmt, long a = 0, long b = 0, long c = 0)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, a, b, c);
+    return std::string(buf);
+}
+
+/*
+ * Invariants of the program itself, by abstract interpretation: every internal node's vector is completed exactly
+ * once, every edge is applied exactly once, the stack is used as a stack inside [0, slots_needed), and the op
+ * arguments name existing nodes / tip slots.  Returns "" when the program is well formed.
+ */
+static inline std::string plk_program_check(int N, const int *ip, const int *ix, const int *preorder,
+                                            const char *node_has_data, const PlkProgram &pg)
+{
+    const int E = N - 1;
+    const int nops = (int)pg.ops.size();
+    if ((int)pg.op_edge.size() != nops) return "program: op_edge size";
+    if ((int)pg.scale_node.size() != N) return "program: scale_node size";
+    if (pg.slots_needed < 0) return "program: negative stack depth";
+    std::vector<int> edge_seen(std::max(E, 1), 0), tip_seen(pg.tip_edge.size(), 0);
+    std::vector<char> slot_full(std::max(pg.slots_needed, 1), 0);
+    int depth = 0;
+    bool have_cur = false;
+    for (int pc = 0; pc < nops; pc++) {
+        const int code = pg.ops[pc].x & 0xff, t = pg.ops[pc].x >> 8, y = pg.ops[pc].y, e = pg.op_edge[pc];
+        switch (code) {
+        case OP_TIP_SET: case OP_TIP_MUL:
+            if (t < 0 || t >= (int)pg.tip_edge.size() || tip_seen[t]++) return plk_fmt("program: op %ld: bad tip slot %ld", pc, t);
+            if (e != pg.tip_edge[t] || e < 0 || e >= E || ix[e] != y) return plk_fmt("program: op %ld: tip edge mismatch", pc);
+            if (ip[y + 1] != ip[y]) return plk_fmt("program: op %ld: tip op on an internal node", pc);
+            if (edge_seen[e]++) return plk_fmt("program: edge %ld applied twice", e);
+            if ((code == OP_TIP_SET) == have_cur) return plk_fmt("program: op %ld: TIP_SET/TIP_MUL does not match the state", pc);
+            have_cur = true;
+            break;
+        case OP_MATVEC:
+            if (e < 0 || e >= E || edge_seen[e]++) return plk_fmt("program: op %ld: bad or repeated edge %ld", pc, e);
+            if (ip[ix[e] + 1] == ip[ix[e]]) return plk_fmt("program: op %ld: MATVEC on a leaf edge", pc);
+            if (!have_cur) return plk_fmt("program: op %ld: MATVEC without a vector", pc);
+            break;
+        case OP_PUSH:
+            if (y != depth || y >= pg.slots_needed || slot_full[y] || !have_cur) return plk_fmt("program: op %ld: bad PUSH to slot %ld (depth %ld)", pc, y, depth);
+            slot_full[y] = 1; depth++; have_cur = false;
+            break;
+        case OP_POPMUL:
+            if (y != depth - 1 || y < 0 || !slot_full[y] || !have_cur) return plk_fmt("program: op %ld: bad POPMUL of slot %ld (depth %ld)", pc, y, depth);
+            slot_full[y] = 0; depth--;
+            break;
+        case OP_NODE_MUL:
+            if (y < 0 || y >= N || ip[y + 1] == ip[y] || !node_has_data[y] || !have_cur) return plk_fmt("program: op %ld: bad NODE_MUL", pc);
+            break;
+        case OP_SCALE:
+            if (y < 0 || y >= N || !pg.scale_node[y] || !have_cur) return plk_fmt("program: op %ld: bad SCALE", pc);
+            break;
+        default:
+            return plk_fmt("program: op %ld: unknown opcode %ld", pc, code);
+        }
+    }
+    if (depth != 0) return "program: stack not empty at the end";
+    if (E > 0 && !have_cur) return "program: no root vector";
+    for (int e = 0; e < E; e++) if (edge_seen[e] != 1) return plk_fmt("program: edge %ld applied %ld times", e, edge_seen[e]);
+    for (size_t r = 0; r < pg.obs_nodes.size(); r++)
+        if (pg.obs_nodes[r] < 0 || pg.obs_nodes[r] >= N) return "program: staged row names a node out of range";
+    (void)preorder;
+    return "";
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* fused k = 4 kernels: int4 program of the C++ interpreter, 32-bit op words of the assembly interpreter           */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+struct PlkFused {
+    std::vector<plk_op4> fops;         /* x = opcode | tip<<8, y = row / slot, z = next observation row, w = matrix index */
+    std::vector<int> mat_edge;         /* CSR edge per matrix of the compact stream (the kernels add one spare) */
+    std::vector<unsigned> words;       /* blocks of 8, END padded, one spare block */
+    int first_row = 0;
+    int asm_first_tip = 0, asm_first_row = 0, asm_second_row = 0;
+    bool asm_ok = false;               /* the assembly interpreter's field widths and stack depth suffice */
+};
+
+static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
+{
+    const int nops = (int)pg.ops.size();
+    std::vector<int> row(N, -1);
+    for (size_t r = 0; r < pg.obs_nodes.size(); r++) row[pg.obs_nodes[r]] = (int)r;
+    /* C++ interpreter: ops are executed in pairs and fetched one pair ahead: even count + one spare pair */
+    const int npad = ((nops + 1) / 2) * 2 + 2;
+    fu.fops.assign(npad, plk_op4{OP_END, 0, 0, 0});
+    fu.mat_edge.clear();
+    int next_row = 0;
+    for (int pc = nops - 1; pc >= 0; pc--) {
+        const plk_op2 o = pg.ops[pc];
+        const int code = o.x & 0xff;
+        plk_op4 f = {o.x, o.y, next_row, 0};
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) { f.y = row[o.y]; next_row = f.y; }
+        fu.fops[pc] = f;
+    }
+    fu.first_row = next_row;
+    for (int pc = 0; pc < nops; pc++)
+        if ((fu.fops[pc].x & 0xff) == OP_MATVEC) { fu.fops[pc].w = (int)fu.mat_edge.size(); fu.mat_edge.push_back(pg.op_edge[pc]); }
+    /* assembly interpreter: 32-bit words {opcode | y<<3 | z<<16} in blocks of 8; an observation op carries the tip
+     * slot of the NEXT observation op (y) and the code row of the one after next (z): the prefetch chain of
+     * plk_fused4_asm.h.  An internal node's own data is an observation on the pseudo tip slot ntips. */
+    const int ntips = (int)pg.tip_edge.size();
+    std::vector<int> obs_t, obs_row;
+    for (int pc = 0; pc < nops; pc++) {
+        const int code = fu.fops[pc].x & 0xff;
+        if (code == OP_TIP_SET || code == OP_TIP_MUL) { obs_t.push_back(fu.fops[pc].x >> 8); obs_row.push_back(fu.fops[pc].y); }
+        else if (code == OP_NODE_MUL) { obs_t.push_back(ntips); obs_row.push_back(fu.fops[pc].y); }
+    }
+    const int nwords = ((nops + 1 + 7) / 8) * 8 + 8;
+    fu.words.assign(nwords, (unsigned)OP_END);
+    size_t oi = 0;
+    bool matvec_since_obs = false;   /* a MATVEC (full wait) ran since the last observation op */
+    for (int pc = 0; pc < nops; pc++) {
+        const int code = fu.fops[pc].x & 0xff;
+        unsigned wv = (unsigned)code;
+        if (code == OP_MATVEC) matvec_since_obs = true;
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+            const unsigned tn = oi + 1 < obs_t.size() ? (unsigned)obs_t[oi + 1] : 0u;
+            const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
+            const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
+                                                   : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
+            wv = oc | (tn << 3) | (rn << 16);
+            matvec_since_obs = false;
+            oi++;
+        } else if (code == OP_PUSH || code == OP_POPMUL) {
+            wv |= (unsigned)fu.fops[pc].y << 3;
+        }
+        fu.words[pc] = wv;
+    }
+    fu.asm_first_tip = obs_t.empty() ? 0 : obs_t[0];
+    fu.asm_first_row = obs_row.empty() ? 0 : obs_row[0];
+    fu.asm_second_row = obs_row.size() > 1 ? obs_row[1] : 0;
+    fu.asm_ok = pg.slots_needed <= 8 && ntips + 1 < 8192 && pg.obs_nodes.size() < 65536;
+}
+
+/* dynamic LDS of the fused ll kernels: tip tables of one category (ntips + the pseudo slot) + staged code rows */
+static inline size_t plk_fused_lds_bytes(const PlkProgram &pg, int nchar, int bytes_per_row)
+{
+    return (size_t)(pg.tip_edge.size() + 1) * nchar * 4 * sizeof(double) + pg.obs_nodes.size() * (size_t)bytes_per_row;
+}
+
+/* the observation sequence of the program: (tip slot incl. pseudo slot, staged row) per observation op */
+static inline void plk_obs_sequence(int N, const PlkProgram &pg, std::vector<int> &slot, std::vector<int> &rowv, std::vector<int> &opc)
+{
+    std::vector<int> row(N, -1);
+    for (size_t r = 0; r < pg.obs_nodes.size(); r++) row[pg.obs_nodes[r]] = (int)r;
+    slot.clear(); rowv.clear(); opc.clear();
+    for (size_t pc = 0; pc < pg.ops.size(); pc++) {
+        const int code = pg.ops[pc].x & 0xff;
+        if (code == OP_TIP_SET || code == OP_TIP_MUL) { slot.push_back(pg.ops[pc].x >> 8); rowv.push_back(row[pg.ops[pc].y]); opc.push_back(code); }
+        else if (code == OP_NODE_MUL) { slot.push_back((int)pg.tip_edge.size()); rowv.push_back(row[pg.ops[pc].y]); opc.push_back(code); }
+    }
+}
+
+/*
+ * Replays k_ll_fused4_asm<D> (plk_fused4_asm.h) on the host: the block-ahead word fetch, the matrix stream that is
+ * always one matrix ahead, the LDS addresses of the tip-value prefetch chain (for the largest code, nchar - 1) and of
+ * the code bytes, the 13-bit / 16-bit fields, the AGPR slot numbers -- and checks that the values the chain delivers
+ * to each observation op are the ones the program asks for.  pack4: two codes per staged byte (nchar <= 16).
+ */
+static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const PlkFused &fu, int nchar, int D, int pack4,
+                                              size_t lds_bytes_launched)
+{
+    const int nops = (int)pg.ops.size(), ntips1 = (int)pg.tip_edge.size() + 1, nobs = (int)pg.obs_nodes.size();
+    const int nmat = (int)fu.mat_edge.size();
+    if (nchar < 1 || nchar > 256) return "asm program: nchar out of range";
+    if (pack4 && nchar > 16) return "asm program: 4-bit codes need nchar <= 16";
+    if (D != 4 && D != 8) return "asm program: stack depth variant";
+    if (pg.slots_needed > D) return "asm program: the tree needs a deeper register stack";
+    if (fu.words.size() % 8 != 0 || (int)fu.words.size() < ((nops + 1 + 7) / 8) * 8 + 8) return "asm program: word buffer too short";
+    const size_t row_bytes = pack4 ? PLK_TILE / 2 : PLK_TILE;
+    const size_t tip_bytes = (size_t)ntips1 * nchar * 32, code_bytes = (size_t)nobs * row_bytes;
+    if (tip_bytes + code_bytes > lds_bytes_launched) return "asm program: LDS image larger than the launch's dynamic LDS";
+    if (lds_bytes_launched > PLK_LDS_LIMIT) return "asm program: dynamic LDS above the limit";
+    if (nobs < 1) return "asm program: no observation rows";
+    std::vector<int> slot, rowv, opc;
+    plk_obs_sequence(N, pg, slot, rowv, opc);
+    auto tip_ok = [&](long t) { return t >= 0 && t < ntips1 && (size_t)t * nchar * 32 + (size_t)(nchar - 1) * 32 + 32 <= tip_bytes; };
+    auto row_ok = [&](long r) { return r >= 0 && r < nobs && (size_t)r * row_bytes + (row_bytes - 1) < code_bytes; };
+    if (!tip_ok(fu.asm_first_tip) || !row_ok(fu.asm_first_row) || !row_ok(fu.asm_second_row)) return "asm program: prologue prefetch out of range";
+    /* prefetch chain state: value in flight = (cur_tip, cur_row), code in flight = next_row */
+    long cur_tip = fu.asm_first_tip, cur_row = fu.asm_first_row, next_row = fu.asm_second_row;
+    size_t oi = 0;
+    int mi = 0;                       /* matrix currently loaded; the kernel loads mi + 1 after each MATVEC */
+    bool waited = true;               /* lgkmcnt(0) seen since the in-flight value was requested (prologue waits) */
+    std::vector<char> full(D, 0);
+    const size_t nblocks = fu.words.size() / 8;
+    for (size_t b = 0;; b++) {
+        if (b + 1 >= nblocks) return "asm program: ran past the spare block (no END)";
+        /* s_load_dwordx8 of block b + 1 is issued here: in range by the test above */
+        for (int i = 0; i < 8; i++) {
+            const unsigned w = fu.words[b * 8 + i];
+            const unsigned oc = w & 7, y = (w >> 3) & 0x1fff, z = w >> 16;
+            const size_t pc = b * 8 + i;
+            if (oc == OP_END) {
+                if ((int)pc != nops) return plk_fmt("asm program: END at word %ld, program has %ld ops", (long)pc, nops);
+                if (oi != slot.size()) return "asm program: observation ops missing";
+                if (mi != nmat) return "asm program: matrix stream not consumed";
+                return "";
+            }
+            if ((int)pc >= nops) return "asm program: op beyond the program";
+            const int code = pg.ops[pc].x & 0xff;
+            switch (oc) {
+            case OP_MATVEC:
+                if (code != OP_MATVEC) return plk_fmt("asm program: word %ld is not the program's op", (long)pc);
+                if (fu.mat_edge[mi] != pg.op_edge[pc]) return plk_fmt("asm program: matrix %ld is not the op's edge", mi);
+                mi++;                                   /* loads matrix mi (<= nmat: the spare) */
+                if (mi > nmat) return "asm program: matrix stream overrun";
+                waited = true;
+                break;
+            case OP_TIP_SET: case OP_TIP_MUL: case PLK_WORD_TIPMUL_NOWAIT: {
+                if (code != OP_TIP_SET && code != OP_TIP_MUL && code != OP_NODE_MUL) return plk_fmt("asm program: word %ld is not an observation op", (long)pc);
+                if ((oc == OP_TIP_SET) != (code == OP_TIP_SET)) return plk_fmt("asm program: word %ld: SET/MUL mismatch", (long)pc);
+                if (oc == PLK_WORD_TIPMUL_NOWAIT && !waited) return plk_fmt("asm program: word %ld skips a wait it needs", (long)pc);
+                if (oi >= slot.size() || cur_tip != slot[oi] || cur_row != rowv[oi]) return plk_fmt("asm program: prefetch chain delivers the wrong observation at word %ld", (long)pc);
+                if (!tip_ok(y) || !row_ok(z)) return plk_fmt("asm program: word %ld prefetches out of range (slot %ld, row %ld)", (long)pc, y, z);
+                cur_tip = y; cur_row = next_row; next_row = z;
+                if (oi + 1 < slot.size() && (cur_tip != slot[oi + 1] || cur_row != rowv[oi + 1])) return plk_fmt("asm program: chain after word %ld", (long)pc);
+                oi++;
+                waited = false;
+                break;
+            }
+            case OP_PUSH:
+                if (code != OP_PUSH || (int)y >= D || (int)y != pg.ops[pc].y || full[y]) return plk_fmt("asm program: bad PUSH at word %ld", (long)pc);
+                full[y] = 1;
+                break;
+            case OP_POPMUL:
+                if (code != OP_POPMUL || (int)y >= D || (int)y != pg.ops[pc].y || !full[y]) return plk_fmt("asm program: bad POPMUL at word %ld", (long)pc);
+                full[y] = 0;
+                break;
+            case OP_SCALE:
+                if (code != OP_SCALE) return plk_fmt("asm program: word %ld is not the program's op", (long)pc);
+                break;
+            default:
+                return plk_fmt("asm program: unknown opcode in word %ld", (long)pc);
+            }
+        }
+        waited = true;                /* s_waitcnt lgkmcnt(0) at the end of every block */
+    }
+}
+
+/* the C++ interpreter k_ll_fused4<D, NS> (plk_fused4.h): pair-ahead fetch, one-ahead code row chain */
+static inline std::string plk_fused_check_cpp(int N, const PlkProgram &pg, const PlkFused &fu, int nchar, int D, int NS,
+                                              size_t lds_bytes_launched)
+{
+    const int nops = (int)pg.ops.size(), ntips1 = (int)pg.tip_edge.size() + 1, nobs = (int)pg.obs_nodes.size();
+    if (D != 4 && D != 8 && D != 16) return "fused program: stack depth variant";
+    if (pg.slots_needed > D) return "fused program: the tree needs a deeper register stack";
+    if (nchar < 1 || nchar > 256) return "fused program: nchar out of range";
+    if ((size_t)ntips1 * nchar * 32 + (size_t)nobs * PLK_TILE * NS > lds_bytes_launched) return "fused program: LDS image larger than the launch's dynamic LDS";
+    if (lds_bytes_launched > PLK_LDS_LIMIT) return "fused program: dynamic LDS above the limit";
+    /* the loop runs over even pc < nops and fetches the pair (pc + 2, pc + 3) while it executes (pc, pc + 1) */
+    const int last_pc = nops > 0 ? ((nops - 1) / 2) * 2 : 0;
+    if (fu.fops.size() < 2 || (nops > 0 && (size_t)(last_pc + 3) >= fu.fops.size())) return "fused program: op buffer too short for the look-ahead";
+    std::vector<int> slot, rowv, opc;
+    plk_obs_sequence(N, pg, slot, rowv, opc);
+    if (fu.first_row < 0 || fu.first_row >= std::max(nobs, 1)) return "fused program: first row out of range";
+    long cur_row = fu.first_row;
+    size_t oi = 0;
+    int mi = 0;
+    for (int pc = 0; pc < nops; pc++) {
+        const plk_op4 f = fu.fops[pc];
+        const int code = f.x & 0xff;
+        if (code != (pg.ops[pc].x & 0xff)) return "fused program: opcode mismatch";
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+            if (oi >= slot.size() || cur_row != rowv[oi]) return plk_fmt("fused program: code chain delivers the wrong row at op %ld", pc);
+            if (code != OP_NODE_MUL && ((f.x >> 8) < 0 || (f.x >> 8) >= ntips1 - 1)) return "fused program: tip slot out of range";
+            if (f.z < 0 || f.z >= nobs) return "fused program: next row out of range";
+            cur_row = f.z;
+            oi++;
+        } else if (code == OP_MATVEC) {
+            if (f.w != mi || fu.mat_edge[mi] != pg.op_edge[pc]) return "fused program: matrix index mismatch";
+            mi++;
+        } else if (code == OP_PUSH || code == OP_POPMUL) {
+            if (f.y < 0 || f.y >= D) return "fused program: stack slot out of range";
+        }
+    }
+    for (size_t pc = nops; pc < fu.fops.size(); pc++) if ((fu.fops[pc].x & 0xff) != OP_END) return "fused program: padding is not END";
+    return "";
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* down passes that traverse the program (k_down_fused4, k_ll_mfma, k_down_fused_mfma): int4 ops with an          */
+/* observation chain (z = tip slot of the next observation op, w = its staged row; the last one wraps with bit 30) */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+struct PlkChain {
+    std::vector<plk_op4> ops;          /* + one trailing OP_END (k_down_fused4 reads one op ahead) */
+    int first_slot = -1, first_row = 0;
+};
+
+/* mode 0: MATVEC keeps (x, y) of the program (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
+ * child node (k_down_fused4); mode 2: as 1 plus w = storage index of the edge (k_down_fused_mfma, no chain).
+ * SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
+static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const int *indices, const int *node_int,
+                                   const int *edge_int, const int *node_scale, PlkChain &ch)
+{
+    const int ntips = (int)pg.tip_edge.size();
+    std::vector<int> row(N, -1);
+    for (size_t r = 0; r < pg.obs_nodes.size(); r++) row[pg.obs_nodes[r]] = (int)r;
+    ch.ops.assign(pg.ops.size() + 1, plk_op4{OP_END, 0, 0, 0});
+    ch.first_slot = -1; ch.first_row = 0;
+    int prev = -1;
+    for (size_t pc = 0; pc < pg.ops.size(); pc++) {
+        const int code = pg.ops[pc].x & 0xff;
+        plk_op4 o = {pg.ops[pc].x, pg.ops[pc].y, 0, 0};
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+            const int slot = code == OP_NODE_MUL ? ntips : (o.x >> 8);
+            o.y = row[pg.ops[pc].y];
+            if (mode != 2) {
+                if (prev < 0) { ch.first_slot = slot; ch.first_row = o.y; }
+                else { ch.ops[prev].z = slot; ch.ops[prev].w = o.y; }
+                prev = (int)pc;
+            }
+        } else if (code == OP_MATVEC && mode >= 1) {
+            o.y = pg.op_edge[pc];
+            o.z = node_int[indices[o.y]];
+            if (mode == 2) o.w = edge_int[o.y];
+        } else if (code == OP_SCALE && mode >= 1) {
+            o.y = node_scale[pg.ops[pc].y];
+        }
+        ch.ops[pc] = o;
+    }
+    if (prev >= 0) { ch.ops[prev].z = ch.first_slot | (1 << 30); ch.ops[prev].w = ch.first_row; }
+}
+
+static inline std::string plk_chain_check(int N, const PlkProgram &pg, const PlkChain &ch, int mode, int D, int nint_nodes,
+                                          int nint_edges, int nscale_slots, int site_block, size_t lds_code_bytes)
+{
+    const int nops = (int)pg.ops.size(), ntips = (int)pg.tip_edge.size(), nobs = (int)pg.obs_nodes.size();
+    if ((int)ch.ops.size() != nops + 1 || (ch.ops[nops].x & 0xff) != OP_END) return "down program: missing END";
+    if (pg.slots_needed > D) return "down program: the tree needs a deeper stack";
+    if ((size_t)nobs * site_block > lds_code_bytes) return "down program: staged code rows exceed the launch's LDS";
+    std::vector<int> slot, rowv, opc;
+    plk_obs_sequence(N, pg, slot, rowv, opc);
+    long cur_slot = ch.first_slot, cur_row = ch.first_row;
+    if (mode != 2 && !slot.empty() && (cur_slot != slot[0] || cur_row != rowv[0])) return "down program: first observation";
+    if (mode != 2 && slot.empty() && ch.first_slot >= 0) return "down program: first observation without observations";
+    size_t oi = 0;
+    for (int pc = 0; pc < nops; pc++) {
+        const plk_op4 o = ch.ops[pc];
+        const int code = o.x & 0xff;
+        if (code != (pg.ops[pc].x & 0xff)) return "down program: opcode mismatch";
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+            if (o.y < 0 || o.y >= nobs || o.y != rowv[oi]) return plk_fmt("down program: op %ld names the wrong staged row", pc);
+            if (code != OP_NODE_MUL && ((o.x >> 8) < 0 || (o.x >> 8) >= ntips)) return "down program: tip slot out of range";
+            if (mode != 2) {
+                const int wrap = (o.z >> 30) & 1, ns = o.z & 0x3fffffff;
+                if (ns < 0 || ns > ntips || o.w < 0 || o.w >= nobs) return plk_fmt("down program: op %ld prefetches out of range", pc);
+                if (cur_slot != slot[oi] || cur_row != rowv[oi]) return plk_fmt("down program: chain delivers the wrong observation at op %ld", pc);
+                const size_t nx = oi + 1 < slot.size() ? oi + 1 : 0;
+                if (wrap != (oi + 1 == slot.size()) || ns != slot[nx] || o.w != rowv[nx]) return plk_fmt("down program: chain link after op %ld", pc);
+                cur_slot = ns; cur_row = o.w;
+            }
+            oi++;
+        } else if (code == OP_MATVEC && mode >= 1) {
+            if (o.y != pg.op_edge[pc] || o.z < 0 || o.z >= nint_nodes) return plk_fmt("down program: op %ld stores to a bad node index", pc);
+            if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
+        } else if (code == OP_PUSH || code == OP_POPMUL) {
+            if (o.y < 0 || o.y >= D) return "down program: stack slot out of range";
+        } else if (code == OP_SCALE && mode >= 1) {
+            if (o.y < -1 || o.y >= nscale_slots) return "down program: rescaling slot out of range";
+        }
+    }
+    if (oi != slot.size()) return "down program: observation count";
+    return "";
+}
+
+#endif

@@ -32,44 +32,35 @@ struct VecArgs {
 
 /* Touch every 64-byte line of the K x K matrix at p with scalar loads whose results are never used.  All waves
  * of a CU walk the same matrix stream (C * nmat * K * K * 8 bytes, far larger than the 16 KB scalar cache), so
- * without this every s_load of the product below waits for L2 (SQC_DCACHE_MISSES + _DUPLICATE = 60 % of the
- * requests); with the lines requested one product ahead the operand loads hit.  The dummy destination is kept
- * allocated until vec_touch_done(). */
-/* 16 lines starting at byte offset BASE; no wait */
-#define VEC_TOUCH16(D, P, BASE)                                                                                   \
-    asm volatile("s_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3\n\ts_load_dword %0, %1, %4\n\ts_load_dword %0, %1, %5\n\t" \
-                 "s_load_dword %0, %1, %6\n\ts_load_dword %0, %1, %7\n\ts_load_dword %0, %1, %8\n\ts_load_dword %0, %1, %9\n\t" \
-                 "s_load_dword %0, %1, %10\n\ts_load_dword %0, %1, %11\n\ts_load_dword %0, %1, %12\n\ts_load_dword %0, %1, %13\n\t" \
-                 "s_load_dword %0, %1, %14\n\ts_load_dword %0, %1, %15\n\ts_load_dword %0, %1, %16\n\ts_load_dword %0, %1, %17" \
-                 : "=&s"(D) : "s"(P), "n"((BASE) + 0x0), "n"((BASE) + 0x40), "n"((BASE) + 0x80), "n"((BASE) + 0xc0),  \
-                   "n"((BASE) + 0x100), "n"((BASE) + 0x140), "n"((BASE) + 0x180), "n"((BASE) + 0x1c0),              \
-                   "n"((BASE) + 0x200), "n"((BASE) + 0x240), "n"((BASE) + 0x280), "n"((BASE) + 0x2c0),              \
-                   "n"((BASE) + 0x300), "n"((BASE) + 0x340), "n"((BASE) + 0x380), "n"((BASE) + 0x3c0) : "memory")
-#define VEC_TOUCH2(D, P, BASE)                                                                                    \
-    asm volatile("s_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3" : "=&s"(D) : "s"(P), "n"((BASE) + 0x0), "n"((BASE) + 0x40) : "memory")
-
-struct VecTouch { unsigned d[9]; };
+ * without this every s_load of a product waits for L2 in turn (SQC_DCACHE_MISSES + _DUPLICATE = 60 % of the
+ * requests); touched one product ahead, all lines of a matrix are requested at once and the operand loads of the
+ * next product hit.
+ *
+ * The loads are WAITED FOR INSIDE THE SAME asm STATEMENT.  Round 1 left them in flight across compiler-generated
+ * code (waiting at the next product): the compiler cannot know that a register named as an asm output is still
+ * going to be written after the statement, and in the generated code it reused those SGPRs at once -- for the
+ * op-word index and address at the loop head in k_ll_vec<16>, for reloaded spilled pointers at the loop exit in
+ * k_ll_vec<20> / <32> -- so a line arriving late replaced an address with matrix bytes: a wild scalar load, i.e.
+ * the intermittent GPU memory fault (process abort) recorded in DESIGN.md section 6.  tools/isa_lint.py now checks
+ * the generated ISA for any scalar load left pending at the end of an asm block. */
+#define VEC_T4(B) "s_load_dword %0, %1, " #B "+0x0\n\ts_load_dword %0, %1, " #B "+0x40\n\t" \
+                  "s_load_dword %0, %1, " #B "+0x80\n\ts_load_dword %0, %1, " #B "+0xc0\n\t"
+#define VEC_T16(B) VEC_T4(B) VEC_T4(B+0x100) VEC_T4(B+0x200) VEC_T4(B+0x300)
+#define VEC_T2(B) "s_load_dword %0, %1, " #B "+0x0\n\ts_load_dword %0, %1, " #B "+0x40\n\t"
 
 template <int K>
-__device__ __forceinline__ VecTouch vec_touch(const PLK_AS4 double *p)
+__device__ __forceinline__ void vec_touch(const PLK_AS4 double *p)
 {
-    VecTouch t = {};
-    constexpr int NL = K * K * 8 / 64;          /* 32 (K = 16), 50 (K = 20), 128 (K = 32) */
-    VEC_TOUCH16(t.d[0], p, 0x0);
-    VEC_TOUCH16(t.d[1], p, 0x400);
-    if constexpr (NL >= 48) VEC_TOUCH16(t.d[2], p, 0x800);
-    if constexpr (NL == 50) VEC_TOUCH2(t.d[3], p, 0xc00);
-    if constexpr (NL >= 64) VEC_TOUCH16(t.d[3], p, 0xc00);
-    if constexpr (NL >= 80) VEC_TOUCH16(t.d[4], p, 0x1000);
-    if constexpr (NL >= 96) VEC_TOUCH16(t.d[5], p, 0x1400);
-    if constexpr (NL >= 112) VEC_TOUCH16(t.d[6], p, 0x1800);
-    if constexpr (NL >= 128) VEC_TOUCH16(t.d[7], p, 0x1c00);
-    return t;
-}
-__device__ __forceinline__ void vec_touch_done(const VecTouch &t)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(t.d[0]), "s"(t.d[1]), "s"(t.d[2]), "s"(t.d[3]), "s"(t.d[4]), "s"(t.d[5]),
-                 "s"(t.d[6]), "s"(t.d[7]) : "memory");
+    unsigned d;
+    static_assert(K == 16 || K == 20 || K == 32, "line count");
+    if constexpr (K == 16)          /* 32 lines */
+        asm volatile(VEC_T16(0x0) VEC_T16(0x400) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+    else if constexpr (K == 20)     /* 50 lines */
+        asm volatile(VEC_T16(0x0) VEC_T16(0x400) VEC_T16(0x800) VEC_T2(0xc00) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+    else                            /* 128 lines */
+        asm volatile(VEC_T16(0x0) VEC_T16(0x400) VEC_T16(0x800) VEC_T16(0xc00) VEC_T16(0x1000) VEC_T16(0x1400) VEC_T16(0x1800)
+                     VEC_T16(0x1c00) "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(p) : "memory");
+    (void)d;
 }
 
 template <int K>
@@ -86,7 +77,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
-    VecTouch td = {};
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -99,7 +89,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
                 const PLK_AS4 double *M = PSc + (size_t)pc * K * K;
-                vec_touch_done(td);      /* the lines requested after the previous product have arrived */
+                /* request (and wait for) the lines of the NEXT product's matrix -- the next category's first one at
+                 * the end -- before multiplying with this one, whose lines the previous product requested */
+                const int nc = oy <= pc ? c + 1 : c;
+                vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oy) * K * K);
                 double acc[K];
 #pragma unroll
                 for (int i = 0; i < K; i++) acc[i] = M[i] * cur[0];
@@ -110,10 +103,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = acc[i];
-                /* request the lines of the next product's matrix (the next category's first one at the end);
-                 * the observation / stack ops in between hide the L2 latency */
-                const int nc = oy <= pc ? c + 1 : c;
-                td = vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oy) * K * K);
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
                 const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
                 const int ch = a.codes[(size_t)oy * a.Spad + sc];
@@ -162,7 +151,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
             else sum += ldexp(term, esc - Eexp);
         }
     }
-    vec_touch_done(td);
     const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
     if (valid && a.site_ll) a.site_ll[s] = ll;
     if (a.partial) {

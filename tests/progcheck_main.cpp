@@ -1,0 +1,188 @@
+/*
+ * tests/progcheck_main.cpp -- CPU driver for the traversal-program builder and the host replays of the device
+ * interpreters (phyly_amd/csrc/plk_program.h), built with AddressSanitizer + UBSan by tests/test_program_check.py.
+ *
+ * usage: progcheck                      seeded random trees of every shape the engine accepts
+ *        progcheck <file>               trees from a file, one per line: "N nchar  a0 b0 a1 b1 ... | h0 h1 ... hN-1"
+ *                                       (edges parent child in user order; h = 1 for nodes that carry data)
+ * For every tree: program build + invariants, fused formats for every kernel variant the engine could launch
+ * (assembly interpreter with 4-bit and 8-bit codes, C++ interpreter with one and two sites per lane), the chained
+ * programs of the three down passes; and negative controls (corrupted words must be refused).
+ * Prints "ok <trees> <ops>" and exits 0, or the first failure and exits 1.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "plk_program.h"
+
+struct Tree { int N; std::vector<int> ip, ix, pre; };
+
+/* CSR + BFS order as host_model.c builds them (src/csr_graph.c:218-229 of the reference: children in user order) */
+static bool make_tree(int N, const std::vector<int> &ea, const std::vector<int> &eb, Tree &t)
+{
+    t.N = N; t.ip.assign(N + 1, 0); t.ix.assign(N > 1 ? N - 1 : 1, 0); t.pre.clear();
+    std::vector<int> indeg(N, 0);
+    for (int e = 0; e < N - 1; e++) { t.ip[ea[e] + 1]++; indeg[eb[e]]++; }
+    for (int a = 0; a < N; a++) t.ip[a + 1] += t.ip[a];
+    std::vector<int> fill(t.ip.begin(), t.ip.end() - 1);
+    for (int e = 0; e < N - 1; e++) t.ix[fill[ea[e]]++] = eb[e];
+    int root = -1;
+    for (int a = 0; a < N; a++) if (!indeg[a]) { if (root >= 0) return false; root = a; }
+    if (root < 0) return false;
+    t.pre.push_back(root);
+    for (size_t h = 0; h < t.pre.size(); h++)
+        for (int idx = t.ip[t.pre[h]]; idx < t.ip[t.pre[h] + 1]; idx++) t.pre.push_back(t.ix[idx]);
+    return (int)t.pre.size() == N;
+}
+
+static long g_ops = 0;
+
+static std::string check_tree(const Tree &t, const std::vector<char> &has, int nchar)
+{
+    const int N = t.N;
+    PlkProgram pg;
+    plk_program_build(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), pg);
+    g_ops += (long)pg.ops.size();
+    std::string bad = plk_program_check(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), pg);
+    if (!bad.empty()) return bad;
+    /* storage indices as run_updown4 / run_updown_mfma compute them */
+    const int E = N - 1, ntips = (int)pg.tip_edge.size();
+    std::vector<int> edge_tip(E, -1), edge_int(E, -1), node_int(N, -1), node_scale(N, -1);
+    for (int k = 0; k < ntips; k++) edge_tip[pg.tip_edge[k]] = k;
+    int nie = 0, nin = 0, nsc = 0;
+    for (int e = 0; e < E; e++) if (edge_tip[e] < 0) edge_int[e] = nie++;
+    for (int a = 0; a < N; a++) if (t.ip[a + 1] > t.ip[a]) node_int[a] = nin++;
+    for (int a = 0; a < N; a++) if (node_int[a] >= 0 && pg.scale_node[a]) node_scale[a] = nsc++;
+    for (int mode = 0; mode <= 2; mode++) {
+        PlkChain ch;
+        plk_chain_build(N, pg, mode, t.ix.data(), node_int.data(), edge_int.data(), node_scale.data(), ch);
+        const int block = mode == 1 ? 256 : 64;
+        bad = plk_chain_check(N, pg, ch, mode, 1 << 30, nin, nie, nsc, block, pg.obs_nodes.size() * (size_t)block);
+        if (!bad.empty()) return "mode " + std::to_string(mode) + ": " + bad;
+        if (mode == 1 && !pg.ops.empty()) {      /* negative control: a broken chain link must be noticed */
+            for (size_t pc = 0; pc < pg.ops.size(); pc++) {
+                const int code = ch.ops[pc].x & 0xff;
+                if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                    PlkChain c2 = ch;
+                    c2.ops[pc].w += 1;
+                    if (plk_chain_check(N, pg, c2, mode, 1 << 30, nin, nie, nsc, block, pg.obs_nodes.size() * (size_t)block).empty())
+                        return "negative control: corrupted chain accepted";
+                    break;
+                }
+            }
+        }
+    }
+    if (pg.slots_needed > PLK_FUSED_SLOTS) return "";
+    PlkFused fu;
+    plk_fused_build(N, pg, fu);
+    for (int NS = 1; NS <= 2; NS++) {
+        const size_t lds = plk_fused_lds_bytes(pg, nchar, PLK_TILE * NS);
+        if (lds > PLK_LDS_LIMIT || (NS == 2 && pg.slots_needed > 8)) continue;
+        const int D = pg.slots_needed <= 4 ? 4 : (pg.slots_needed <= 8 ? 8 : 16);
+        bad = plk_fused_check_cpp(N, pg, fu, nchar, D, NS, lds);
+        if (!bad.empty()) return "NS " + std::to_string(NS) + ": " + bad;
+    }
+    if (fu.asm_ok) {
+        for (int pack4 = 0; pack4 <= 1; pack4++) {
+            if (pack4 && nchar > 16) continue;
+            const size_t lds = plk_fused_lds_bytes(pg, nchar, pack4 ? PLK_TILE / 2 : PLK_TILE);
+            if (lds > PLK_LDS_LIMIT) continue;
+            const int D = pg.slots_needed <= 4 ? 4 : 8;
+            bad = plk_fused_check_asm(N, pg, fu, nchar, D, pack4, lds);
+            if (!bad.empty()) return "pack4 " + std::to_string(pack4) + ": " + bad;
+            /* negative controls: one byte less of LDS, a field pushed out of range, a lost END */
+            if (plk_fused_check_asm(N, pg, fu, nchar, D, pack4, lds - 1).empty()) return "negative control: short LDS accepted";
+            PlkFused f2 = fu;
+            bool touched = false;
+            for (size_t w = 0; w < f2.words.size() && !touched; w++)
+                if ((f2.words[w] & 7) <= 1) { f2.words[w] = (f2.words[w] & 0xffff) | ((unsigned)pg.obs_nodes.size() << 16); touched = true; }
+            if (touched && plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: row field out of range accepted";
+            f2 = fu;
+            f2.words[pg.ops.size()] = OP_SCALE;      /* END overwritten */
+            if (plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: missing END accepted";
+        }
+    }
+    return "";
+}
+
+int main(int argc, char **argv)
+{
+    long ntrees = 0;
+    if (argc > 1) {
+        FILE *f = fopen(argv[1], "r");
+        if (!f) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
+        int N, nchar;
+        while (fscanf(f, "%d %d", &N, &nchar) == 2) {
+            if (N < 2) return 2;
+            std::vector<int> ea(N - 1), eb(N - 1);
+            for (int e = 0; e < N - 1; e++) if (fscanf(f, "%d %d", &ea[e], &eb[e]) != 2) return 2;
+            char bar[4];
+            if (fscanf(f, "%3s", bar) != 1 || bar[0] != '|') return 2;
+            std::vector<char> has(N);
+            for (int a = 0; a < N; a++) { int v; if (fscanf(f, "%d", &v) != 1) return 2; has[a] = (char)v; }
+            Tree t;
+            if (!make_tree(N, ea, eb, t)) { fprintf(stderr, "tree %ld is not a rooted tree\n", ntrees); return 1; }
+            for (int a = 0; a < N; a++) if (t.ip[a + 1] == t.ip[a]) has[a] = 0;   /* leaves are tips, not NODE_MUL */
+            const std::string bad = check_tree(t, has, nchar);
+            if (!bad.empty()) { fprintf(stderr, "tree %ld (N = %d, nchar = %d): %s\n", ntrees, N, nchar, bad.c_str()); return 1; }
+            ntrees++;
+        }
+        fclose(f);
+        printf("ok %ld %ld\n", ntrees, g_ops);
+        return 0;
+    }
+    std::mt19937_64 rng(20250355);
+    auto rnd = [&](int n) { return (int)(rng() % (unsigned long long)n); };
+    const int nchars[] = {1, 2, 5, 16, 17, 64, 255, 256};
+    for (int iter = 0; iter < 6000; iter++) {
+        const int shape = iter % 8;
+        int N;
+        if (shape == 7) N = 2 + rnd(3);
+        else if (iter % 97 == 0) N = 500 + rnd(3000);
+        else N = 2 + rnd(iter % 5 == 0 ? 300 : 40);
+        std::vector<int> ea(N - 1), eb(N - 1), label(N);
+        for (int i = 0; i < N; i++) label[i] = i;
+        for (int i = N - 1; i > 0; i--) std::swap(label[i], label[rnd(i + 1)]);
+        for (int i = 1; i < N; i++) {
+            int parent;
+            switch (shape) {
+            case 0: parent = rnd(i); break;                                   /* random recursive tree (multifurcating) */
+            case 1: parent = i - 1; break;                                    /* chain: every node has one child */
+            case 2: parent = (i - 1) / 2; break;                              /* complete binary */
+            case 3: parent = i % 2 ? i - 1 - (i > 1) : i - 2; if (parent < 0) parent = 0; break;   /* caterpillar */
+            case 4: parent = 0; break;                                        /* star */
+            case 5: parent = rnd(10) < 7 ? rnd(i) : std::max(0, i - 1 - rnd(std::min(i, 3))); break;  /* the differential generator's mix */
+            case 6: parent = (i - 1) / 3; break;                              /* ternary */
+            default: parent = rnd(i); break;
+            }
+            ea[i - 1] = label[parent]; eb[i - 1] = label[i];
+        }
+        for (int e = N - 2; e > 0; e--) { const int j = rnd(e + 1); std::swap(ea[e], ea[j]); std::swap(eb[e], eb[j]); }
+        Tree t;
+        if (!make_tree(N, ea, eb, t)) { fprintf(stderr, "generator produced a non-tree\n"); return 2; }
+        std::vector<char> has(N, 0);
+        const int pdata = iter % 3 == 0 ? 0 : (iter % 3 == 1 ? 30 : 100);
+        for (int a = 0; a < N; a++) has[a] = t.ip[a + 1] > t.ip[a] && rnd(100) < pdata;
+        const std::string bad = check_tree(t, has, nchars[rnd(8)]);
+        if (!bad.empty()) { fprintf(stderr, "iteration %d (shape %d, N = %d): %s\n", iter, shape, N, bad.c_str()); return 1; }
+        ntrees++;
+    }
+    /* deep stacks: complete binary trees up to 4096 leaves (stack depth beyond every register variant) */
+    for (int d = 2; d <= 12; d++) {
+        const int N = (1 << (d + 1)) - 1;
+        std::vector<int> ea(N - 1), eb(N - 1);
+        for (int i = 1; i < N; i++) { ea[i - 1] = (i - 1) / 2; eb[i - 1] = i; }
+        Tree t;
+        make_tree(N, ea, eb, t);
+        std::vector<char> has(N, 0);
+        const std::string bad = check_tree(t, has, 5);
+        if (!bad.empty()) { fprintf(stderr, "balanced depth %d: %s\n", d, bad.c_str()); return 1; }
+        ntrees++;
+    }
+    printf("ok %ld %ld\n", ntrees, g_ops);
+    return 0;
+}

@@ -73,3 +73,40 @@ def test_random_queries_under_sanitizers(binary, tmp_path, kind, seed):
     r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
     out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
     assert r.returncode == 0, (out[-500:], err[-3000:])
+
+
+def test_compaction_of_probability_arrays_under_sanitizers(binary, tmp_path):
+    """the 256-entry definition table of parse_probability_array (phyly_amd/csrc/host_model.c): exactly 256 distinct
+    rows, 257 (dense fallback), 0.0 / -0.0 rows, one site, and the dense layout forced by ARBPLF_COMPACT_DENSE=0"""
+    import json
+    import random
+    rng = random.Random(5)
+    files = []
+    for i, nrows in enumerate([1, 4, 16, 17, 255, 256, 257, 400]):
+        n_nodes, k = 4, 3
+        S = -(-nrows // n_nodes)
+        rows = [[round(rng.random(), 6) + 0.01 for _ in range(k)] for _ in range(S * n_nodes)]
+        for r in range(nrows, S * n_nodes):
+            rows[r] = rows[0]
+        pa = [rows[s * n_nodes:(s + 1) * n_nodes] for s in range(S)]
+        if i == 2:
+            pa[0][1] = [0.0, 1.0, 0.0]
+            pa[0][2] = [-0.0, 1.0, -0.0]
+        x = {"model_and_data": {"edges": [[0, 1], [0, 2], [0, 3]], "edge_rate_coefficients": [0.1, 0.2, 0.3],
+                                "rate_matrix": [[0, 1, 1], [1, 0, 1], [1, 1, 0]], "probability_array": pa},
+             "site_reduction": {"aggregation": "sum"}}
+        f = tmp_path / ("c%d.json" % i)
+        f.write_text(json.dumps(x))
+        files.append(str(f))
+    for dense in (None, "0"):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+                   FAKE_ENGINE="1")
+        env.pop("ARBPLF_COMPACT_DENSE", None)
+        if dense:
+            env["ARBPLF_COMPACT_DENSE"] = dense
+        for kind in ("ll", "deriv", "marginal"):
+            r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
+            out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
+            assert r.returncode == 0, (dense, kind, out[-500:], err[-3000:])
+            last = out.strip().splitlines()[-1].split()
+            assert int(last[3]) == len(files), out[-300:]
