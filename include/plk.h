@@ -202,6 +202,44 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
        PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
                            33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */ };
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.
+ *
+ * Sites are independent given (tree, Q, rates); the only cross-site operations of the reference are the axis
+ * reductions of nd_accum_accumulate (src/ndaccum.c:198-254) at the end of the site loops (src/arbplfll.c:139-170,
+ * src/arbplfderiv.c:329-356, src/arbplfmarginal.c:237-256).  A group therefore gives engine i the contiguous block
+ * [i*ceil(S/G), min(S, (i+1)*ceil(S/G))) of the site patterns (and of the weights), runs the engines concurrently
+ * (one host thread each), returns per-site outputs at their global positions and adds the {hi, lo} partial sums of
+ * the engines in engine order (long double): ll (2 doubles), edge sums (2E), node/state sums (2Nk), Hessian (2EE).
+ * Deterministic for a given device list.  Every engine computes the same transition matrices itself (cheaper than
+ * moving them).  The same device may be listed more than once (two engines then share it).
+ * The host drivers (arbplf-ll and friends) build their group from the environment: ARBPLF_DEVICES=0,1,2,...
+ * (default: ARBPLF_DEVICE or device 0).  Host buffers only; every call is synchronous.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct plk_group plk_group;
+
+int plk_group_create(plk_group **out, int ndev, const int *devices);
+void plk_group_destroy(plk_group *g);
+const char *plk_group_last_error(const plk_group *g);
+int plk_group_size(const plk_group *g);
+plk_engine *plk_group_engine(plk_group *g, int i);           /* for plk_set_option / plk_get_info */
+/* site block of engine i as set by the last plk_group_set_patterns_*: [*s0, *s1) */
+int plk_group_block(const plk_group *g, int i, long *s0, long *s1);
+
+int plk_group_set_tree(plk_group *g, int N, const int *indptr, const int *indices, const int *preorder);
+int plk_group_set_model(plk_group *g, int k, int C, const double *Qn, const double *Qn_lo, const double *edge_rates_csr,
+                        const double *cat_rates, const double *cat_prior, int root_mode, const double *root_w);
+int plk_group_update_edge_rates(plk_group *g, const double *edge_rates_csr);
+int plk_group_set_patterns_codes(plk_group *g, long S, const uint8_t *codes /* [N][S] host */, int nchar, const double *defs);
+int plk_group_set_patterns_dense(plk_group *g, long S, const double *B /* [N][k][S] host */);
+int plk_group_set_site_weights(plk_group *g, const double *w /* [S] host or NULL */);
+int plk_group_ll(plk_group *g, double *site_ll_out, double *sum_out);
+int plk_group_deriv(plk_group *g, const int *edge_mask, double *site_edge_out, double *edge_sums_out);
+int plk_group_marginal(plk_group *g, const int *node_mask, double *site_out, double *sums_out);
+int plk_group_edge_expect_multi(plk_group *g, int nL, const double *L_hi, const double *L_lo, int coef_mode,
+                                const int *edge_mask, double *site_out, double *sums_out);
+int plk_group_hess(plk_group *g, double *hess_sums_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,26 +22,44 @@
 #include "host_model.h"
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static plk_engine *g_eng = NULL;
+static plk_group *g_grp = NULL;
+static char g_grp_spec[256];
 
-static plk_engine *get_engine(void)
+/* The engines of this process: one per entry of ARBPLF_DEVICES (comma separated device ids; a device may be listed
+ * twice), else the single device ARBPLF_DEVICE, else device 0.  The site patterns of a query are cut into one
+ * contiguous block per engine (plk_group_*, host_group.c).  The group is cached across queries and rebuilt when the
+ * environment names another device list. */
+static plk_group *get_group(void)
 {
-    if (!g_eng) {
-        int dev = 0;
-        const char *e = getenv("ARBPLF_DEVICE");
-        if (e && *e) dev = atoi(e);
-        if (plk_create(&g_eng, dev)) {
-            fprintf(stderr, "error: %s\n", plk_create_error());
-            g_eng = NULL;
+    const char *list = getenv("ARBPLF_DEVICES"), *one = getenv("ARBPLF_DEVICE");
+    const char *spec = list && *list ? list : (one && *one ? one : "0");
+    if (g_grp && strncmp(spec, g_grp_spec, sizeof g_grp_spec)) { plk_group_destroy(g_grp); g_grp = NULL; }
+    if (!g_grp) {
+        int dev[64], n = 0;
+        const char *p = spec;
+        while (*p && n < 64) {
+            char *end;
+            long v = strtol(p, &end, 10);
+            if (end == p || v < 0 || v > 1023) { fprintf(stderr, "error: ARBPLF_DEVICES: expected a comma separated list of device ids\n"); return NULL; }
+            dev[n++] = (int)v;
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
         }
+        if (n == 0 || *p) { fprintf(stderr, "error: ARBPLF_DEVICES: expected 1 to 64 device ids\n"); return NULL; }
+        if (plk_group_create(&g_grp, n, dev)) {
+            fprintf(stderr, "error: %s\n", plk_create_error());
+            g_grp = NULL;
+            return NULL;
+        }
+        snprintf(g_grp_spec, sizeof g_grp_spec, "%s", spec);
     }
-    return g_eng;
+    return g_grp;
 }
 
 void arbplf_shutdown(void)
 {
     pthread_mutex_lock(&g_mu);
-    if (g_eng) { plk_destroy(g_eng); g_eng = NULL; }
+    if (g_grp) { plk_group_destroy(g_grp); g_grp = NULL; }
     pthread_mutex_unlock(&g_mu);
 }
 
@@ -58,7 +76,7 @@ typedef struct {
     long *usites;      /* unique selected sites, ascending */
     long *site_to_u;   /* S entries, -1 when not selected */
     long double *w_site, div_site;  /* per-site aggregation weights (S) */
-    plk_engine *eng;
+    plk_group *eng;    /* the engines of this query: one site block per device */
 } query;
 
 static void query_init(query *q)
@@ -81,7 +99,7 @@ static void query_clear(query *q)
     free(q->pair_first); free(q->pair_second);
 }
 
-#define ENG(q, call) do { if (call) { fprintf(stderr, "error: %s\n", plk_last_error((q)->eng)); return -1; } } while (0)
+#define ENG(q, call) do { if (call) { fprintf(stderr, "error: %s\n", plk_group_last_error((q)->eng)); return -1; } } while (0)
 
 /* K0 + engine set-up + upload of the selected sites; returns 0 / -1 */
 static int query_prepare(query *q)
@@ -149,11 +167,11 @@ static int query_prepare(query *q)
     for (int i = 0; i < k * k; i++)
         if (!isfinite(q->Qn[i])) { fprintf(stderr, "error: the normalised rate matrix is not finite (zero rate divisor or singular equilibrium system)\n"); return -1; }
 
-    q->eng = get_engine();
+    q->eng = get_group();
     if (!q->eng) return -1;
-    ENG(q, plk_set_tree(q->eng, N, m->indptr, m->indices, m->preorder));
+    ENG(q, plk_group_set_tree(q->eng, N, m->indptr, m->indices, m->preorder));
     const double *root_w = m->root_mode == HM_ROOT_CUSTOM ? m->root_custom : (m->root_mode == HM_ROOT_EQUILIBRIUM ? q->pi : NULL);
-    ENG(q, plk_set_model(q->eng, k, q->C, q->Qn, q->Qn_lo, m->edge_rates_csr, q->cat_rates, q->cat_prior, m->root_mode, root_w));
+    ENG(q, plk_group_set_model(q->eng, k, q->C, q->Qn, q->Qn_lo, m->edge_rates_csr, q->cat_rates, q->cat_prior, m->root_mode, root_w));
 
     /* observations of the selected sites, device layout (site fastest) */
     const long U = q->U;
@@ -164,7 +182,7 @@ static int query_prepare(query *q)
             const uint8_t *src = m->codes8 + (size_t)q->usites[u] * N;
             for (int a = 0; a < N; a++) codes[(size_t)a * U + u] = src[a];
         }
-        int rc = plk_set_patterns_codes(q->eng, U, codes, PLK_HOST, m->nchar, m->defs);
+        int rc = plk_group_set_patterns_codes(q->eng, U, codes, m->nchar, m->defs);
         free(codes);
         ENG(q, rc);
     } else {
@@ -175,7 +193,7 @@ static int query_prepare(query *q)
             for (int a = 0; a < N; a++)
                 for (int j = 0; j < k; j++) B[((size_t)a * k + j) * U + u] = src[(size_t)a * k + j];
         }
-        int rc = plk_set_patterns_dense(q->eng, U, B, PLK_HOST);
+        int rc = plk_group_set_patterns_dense(q->eng, U, B);
         free(B);
         ENG(q, rc);
     }
@@ -187,7 +205,7 @@ static int query_prepare(query *q)
         for (long s = 0; s < S; s++) if (q->site_to_u[s] >= 0) wp[q->site_to_u[s]] += q->w_site[s];
         for (long u = 0; u < U; u++) w[u] = (double)wp[u];
         free(wp);
-        int rc = plk_set_site_weights(q->eng, w, PLK_HOST);
+        int rc = plk_group_set_site_weights(q->eng, w);
         free(w);
         ENG(q, rc);
     }
@@ -259,7 +277,7 @@ static int run_ll(const jval *root, jbuf *out)
     table_begin(out, names, reds, 1);
     if (q.r_site.agg_mode != AGG_NONE) {
         double sum[2] = {0, 0};
-        if (q.U > 0 && plk_ll(q.eng, NULL, PLK_HOST, sum)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (q.U > 0 && plk_group_ll(q.eng, NULL, sum)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
         double v = clean(((long double)sum[0] + (long double)sum[1]) / q.div_site);
         if (check_finite(v, "the aggregated log likelihood")) goto done;
         jbuf_puts(out, "[");
@@ -268,7 +286,7 @@ static int run_ll(const jval *root, jbuf *out)
     } else {
         site_ll = malloc((size_t)(q.U + 1) * sizeof(double));
         if (!site_ll) goto done;
-        if (q.U > 0 && plk_ll(q.eng, site_ll, PLK_HOST, NULL)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (q.U > 0 && plk_group_ll(q.eng, site_ll, NULL)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
         for (int i = 0; i < q.r_site.selection_len; i++) {
             int s = q.r_site.selection[i];
             double v = clean(site_ll[q.site_to_u[s]]);
@@ -308,11 +326,11 @@ static int run_deriv(const jval *root, jbuf *out)
     if (site_agg) {
         sums = calloc((size_t)E * 2 + 2, sizeof(double));
         if (!sums) goto done;
-        if (q.U > 0 && re->selection_len > 0 && plk_deriv(q.eng, mask, NULL, sums)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (q.U > 0 && re->selection_len > 0 && plk_group_deriv(q.eng, mask, NULL, sums)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
     } else {
         vals = calloc((size_t)q.U * E + 1, sizeof(double));
         if (!vals) goto done;
-        if (q.U > 0 && re->selection_len > 0 && plk_deriv(q.eng, mask, vals, NULL)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (q.U > 0 && re->selection_len > 0 && plk_group_deriv(q.eng, mask, vals, NULL)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
     }
     const char *names[] = {"site", "edge"};
     const host_reduction *reds[] = {&q.r_site, re};
@@ -383,11 +401,11 @@ static int run_marginal(const jval *root, jbuf *out)
     if (site_agg) {
         sums = calloc((size_t)N * k * 2 + 2, sizeof(double));
         if (!sums) goto done;
-        if (need && plk_marginal(q.eng, mask, NULL, sums)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (need && plk_group_marginal(q.eng, mask, NULL, sums)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
     } else {
         vals = calloc((size_t)q.U * N * k + 1, sizeof(double));
         if (!vals) goto done;
-        if (need && plk_marginal(q.eng, mask, vals, NULL)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (need && plk_group_marginal(q.eng, mask, vals, NULL)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
     }
     const char *names[] = {"site", "node", "state"};
     const host_reduction *reds[] = {&q.r_site, rn, rs};
@@ -510,8 +528,8 @@ static int run_edge_expect(const jval *root, jbuf *out, int kind)
     else vals_all = calloc((size_t)q.U * npass * E + 1, sizeof(double));
     if (!sums_all && !vals_all) goto done;
     if (q.U > 0 && re->selection_len > 0 && npass > 0 &&
-        plk_edge_expect_multi(q.eng, npass, Lall_hi, Lall_lo, coef, mask, vals_all, sums_all)) {
-        fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done;
+        plk_group_edge_expect_multi(q.eng, npass, Lall_hi, Lall_lo, coef, mask, vals_all, sums_all)) {
+        fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done;
     }
 #define EXP_SUM(t, ce) (((long double)sums_all[((size_t)(t) * E + (ce)) * 2] + (long double)sums_all[((size_t)(t) * E + (ce)) * 2 + 1]) / q.div_site)
 #define EXP_VAL(t, u, ce) ((long double)vals_all[((size_t)(u) * npass + (t)) * E + (ce)])
@@ -604,7 +622,7 @@ static int run_em_update(const jval *root, jbuf *out)
         /* both expectations in one call: [2][E][2] sums (dwell first) */
         both = calloc((size_t)E * 4 + 4, sizeof(double));
         if (!both) goto done;
-        if (plk_edge_expect_multi(q.eng, 2, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, both)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+        if (plk_group_edge_expect_multi(q.eng, 2, Lhi, Llo, PLK_COEF_PRIOR_RATE, NULL, NULL, both)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
         memcpy(dw, both, (size_t)E * 2 * sizeof(double));
         memcpy(tr, both + (size_t)E * 2, (size_t)E * 2 * sizeof(double));
     }
@@ -641,7 +659,7 @@ static int run_hess(const jval *root, jbuf *out)
     const int E = q.m.E;
     hs = calloc((size_t)E * E * 2 + 2, sizeof(double));
     if (!hs) goto done;
-    if (q.U > 0 && E > 0 && plk_hess(q.eng, hs)) { fprintf(stderr, "error: %s\n", plk_last_error(q.eng)); goto done; }
+    if (q.U > 0 && E > 0 && plk_group_hess(q.eng, hs)) { fprintf(stderr, "error: %s\n", plk_group_last_error(q.eng)); goto done; }
     jbuf_puts(out, "{\"columns\": [\"first_edge\", \"second_edge\", \"value\"], \"data\": [");
     for (int a = 0; a < E; a++)
         for (int b = 0; b < E; b++) {

@@ -17,11 +17,11 @@
  * succeed and fill their outputs with constants of the documented shapes, so that the drivers' table code runs under
  * the sanitizers; otherwise plk_create fails and the drivers' error paths run. ---- */
 struct plk_engine { int N, E, k, C; long S; };
-static struct plk_engine g_fake;
 static int fake_on(void) { const char *e = getenv("FAKE_ENGINE"); return e && *e == '1'; }
 const char *plk_create_error(void) { return "stub: no engine in the sanitizer build"; }
-int plk_create(plk_engine **out, int device) { (void)device; if (!fake_on()) { *out = NULL; return PLK_E_DEVICE; } *out = &g_fake; return PLK_OK; }
-void plk_destroy(plk_engine *h) { (void)h; }
+int plk_create(plk_engine **out, int device) { (void)device; if (!fake_on()) { *out = NULL; return PLK_E_DEVICE; } *out = calloc(1, sizeof(struct plk_engine)); return *out ? PLK_OK : PLK_E_NOMEM; }
+void plk_destroy(plk_engine *h) { free(h); }
+int plk_update_edge_rates(plk_engine *h, const double *r) { (void)h; return r ? PLK_OK : PLK_E_ARG; }
 const char *plk_last_error(const plk_engine *h) { (void)h; return "stub"; }
 int plk_set_tree(plk_engine *h, int N, const int *a, const int *b, const int *c) { (void)a; (void)b; (void)c; h->N = N; h->E = N - 1; return PLK_OK; }
 int plk_set_model(plk_engine *h, int k, int C, const double *a, const double *b, const double *c, const double *d,

@@ -70,9 +70,13 @@ def test_random_queries_under_sanitizers(binary, tmp_path, kind, seed):
         files.append(str(f))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                FAKE_ENGINE="1")
-    r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
-    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
-    assert r.returncode == 0, (out[-500:], err[-3000:])
+    for devices in (None, "0,1,2"):      # one engine; three engines (site blocks, threads, partial-sum reduction)
+        env.pop("ARBPLF_DEVICES", None)
+        if devices:
+            env["ARBPLF_DEVICES"] = devices
+        r = subprocess.run([binary, kind] + files, capture_output=True, env=env, timeout=600)
+        out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
+        assert r.returncode == 0, (devices, out[-500:], err[-3000:])
 
 
 def test_compaction_of_probability_arrays_under_sanitizers(binary, tmp_path):
