@@ -3,11 +3,19 @@
 bench.py -- sites/sec of the arbplf-ll hot path on MI355X (BASELINE.json metric).
 
 One "step" = one full pass of the ll path over the rank's resident site
-patterns: exp(Q r t) for every (category, edge) (K1), traversal-program
-matrix stream + tip tables, the pruning kernel over all sites with category
-mixing and log (K2+K3), the weighted site reduction (K7) and, for N > 1, one
-RCCL all-reduce of the double-double log-likelihood sum (X1).  Pattern codes
-are resident in HBM before the timed region.
+patterns: exp(Q r t) for every (category, edge) (K1, which for k = 4 also
+writes the matrix stream and the tip tables), the pruning kernel over all
+sites with category mixing and log (K2+K3), the weighted site reduction (K7)
+and, for N > 1, one RCCL all-reduce of the double-double log-likelihood sum
+(X1).  Pattern codes are resident in HBM before the timed region.  Steps are
+queued on the framework's stream (plk_ll_async): the {hi, lo} sum stays in
+device memory, the all-reduce works on it there, and the host reads the last
+sum after the timed region; the traversal kernel's time is taken from HIP
+events on that same stream around every launch of the timed region.
+
+After the ll region a short edge-gradient leg (arbplf-deriv: down + up pass,
+site-summed, 2E doubles all-reduced for N > 1) is timed and reported under
+"deriv"; it is not part of `value`.
 
 Launch: `python bench.py` (1 GPU) or
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
@@ -52,9 +60,15 @@ def cpu_baseline(workload, sample_sites, seconds=15.0):
     t0 = time.perf_counter()
     ll, used = O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
     dt = time.perf_counter() - t0
+    # the same port on ONE host thread, on a sample sized for a few seconds
+    n1 = max(256, min(n, int(n * 4.0 / max(dt, 1e-3) / max(int(used), 1))) // 256 * 256)
+    t1 = time.perf_counter()
+    O.site_ll(m, w, codes=codes[:n1], defs=workload.defs, precise=0, nthreads=1)
+    dt1 = time.perf_counter() - t1
     return dict(value=n / dt, unit="sites/s", cores=int(used), kind="port",
                 sample="%d sites (the first %d sites of the same synthetic alignment, repeated), double-precision "
-                       "oracle port, %d OpenMP threads, %.1f s" % (n, probe, used, dt)), ll
+                       "oracle port, %d OpenMP threads, %.1f s" % (n, probe, used, dt),
+                one_thread=dict(value=n1 / dt1, unit="sites/s", cores=1, sample="%d sites, %.1f s" % (n1, dt1))), ll
 
 
 def main():
@@ -67,6 +81,9 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
     ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
+    ap.add_argument("--deriv-steps", type=int, default=3, help="steps of the edge-gradient leg (0 = skip)")
+    ap.add_argument("--deriv-sites", type=int, default=0, help="sites of the edge-gradient leg (default: min(sites, 2M))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -78,8 +95,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the engine has no CPU path")
@@ -106,54 +125,99 @@ def main():
     del codes
     torch.cuda.empty_cache()
 
+    # the engine issues its kernels on torch's current stream: the all-reduce and the fences below are ordered with them
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
     red = torch.zeros(2, dtype=torch.float64, device=dev)
 
     def step():
-        eng.update_edge_rates(wl.edge_rates_csr)       # forces K1 + stream + tips
-        _, (hi, lo) = eng.ll(per_site=False, want_sum=True)
-        if world > 1:
-            red[0], red[1] = hi, lo
+        eng.update_edge_rates(wl.edge_rates_csr)       # new rates: K1 (+ stream + tip tables) runs again
+        eng.ll_async(sum_device_ptr=red.data_ptr())    # {hi, lo} of this rank's block, left on the device
+        if use_dist:
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
-            hi, lo = red.tolist()
-        return hi + lo
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    total = None
     for _ in range(args.warmup):
-        total = step()
-    kern_ns = []
+        step()
     fence()
+    eng.info(E.INFO_LL_KERNEL_NS_SUM)                  # reset the event sums
+    eng.info(E.INFO_LL_KERNEL_COUNT)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = step()
-        kern_ns.append(eng.info(E.INFO_LL_KERNEL_NS))
+        step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    kern_ns_sum, kern_count = eng.info(E.INFO_LL_KERNEL_NS_SUM), eng.info(E.INFO_LL_KERNEL_COUNT)
+    assert kern_count == args.steps, (kern_count, args.steps)
+    total = float(red.sum().item())
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # edge-gradient leg: arbplf-deriv on a block of the same sites (site-summed gradient, reduced across ranks)
+    deriv_out = None
+    if args.deriv_steps > 0:
+        from phyly_amd import shard
+        Sd = args.deriv_sites or min(S, 2_000_000)
+        if Sd != S:
+            cd = torch.empty((wl.N, Sd), dtype=torch.uint8, device=dev)
+            for off in range(0, Sd, chunk):
+                n = min(chunk, Sd - off)
+                cd[:, off:off + n] = wl.simulate(n, site0=rank * S + off, device=dev)
+            torch.cuda.synchronize()
+            eng.set_patterns_codes(cd.data_ptr(), wl.defs, S=Sd, where=E.DEVICE)
+            del cd
+        grad = None
+
+        def dstep():
+            eng.update_edge_rates(wl.edge_rates_csr)
+            _, sums = eng.deriv(per_site=False)
+            return shard.allreduce_dd(sums, dev)          # one all-reduce of the 2E {hi, lo} words when distributed
+
+        dstep()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.deriv_steps):
+            grad = dstep()
+        fence()
+        dd_t = time.perf_counter() - t1
+        if use_dist:
+            tmax = torch.tensor([dd_t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dd_t = float(tmax.item())
+        alg_d = wl.algorithmic()
+        deriv_out = dict(value=world * Sd * args.deriv_steps / dd_t, unit="sites/s", sites_per_gpu=Sd, steps=args.deriv_steps,
+                         ms_per_step=dd_t / args.deriv_steps * 1e3, grad_max=float(np.abs(np.asarray(grad)).max()),
+                         hbm_model_bytes_per_site=alg_d["A_deriv"],
+                         hbm_model_frac=alg_d["A_deriv"] * Sd * args.deriv_steps / dd_t / HBM_PEAK,
+                         note="whole arbplf-deriv step (K1, tables, down pass, up pass, weighted site sums%s); "
+                              "A_deriv = 6(I-1)Ck*8 + N of SURVEY.md 8d against 8 TB/s" % (", all-reduce of 2E doubles" if use_dist else ""))
+
     if rank == 0:
         alg = wl.algorithmic()
         kernel_kind = eng.info(E.INFO_LL_KERNEL)
-        kern_s = float(np.mean(kern_ns)) * 1e-9
+        kern_s = kern_ns_sum / kern_count * 1e-9
         value = world * S * args.steps / dt
         hbm_equiv = alg["A_ll"] * S / kern_s
         flops = alg["W_ll"] * S / kern_s
+        kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
+        # HBM bytes per launch from the PMC passes of the guide's recipe (profiles/traffic_cfgN.json, written by
+        # tools/pmc_traffic.py from rocprofv3 --pmc runs of this kernel).  Only used when the file was measured on the
+        # kernel that ran here, at this site count; anything else is reported as null rather than a stale number.
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_cfg%d.json" % args.config)
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                if str(tj.get("kernel", "")).startswith(kname) and int(tj.get("sites", -1)) == S:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
         hbm_model = dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=hbm_equiv / HBM_PEAK,
                          note="A_ll=%d B/site of the HBM-resident-partials design (SURVEY.md 8d)" % alg["A_ll"])
         # which roof binds the kernel that ran: the fused and the matrix-core kernels keep the
@@ -161,10 +225,14 @@ def main():
         # the generic vector kernel streams its stack slots through HBM.
         fp64_bound = kernel_kind in (1, 3, 4) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
         if fp64_bound:
-            roofline = dict(bound="mfma", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
+            roofline = dict(bound="fp64", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
                             frac=flops / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
-                            note="fp64 FMA peak (vector = fp64 MFMA dense peak = 78.6 TFLOP/s on MI355X); "
-                                 "achieved = algorithmic flops W_ll=%d/site x sites / kernel time" % alg["W_ll"],
+                            note="fp64 FMA roof: 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz, AMD's "
+                                 "public MI355X figure for fp64 vector and fp64 matrix alike (SURVEY.md 8d; "
+                                 "MI355X_MICROARCH.md lists no fp64 peak); achieved = algorithmic flops W_ll=%d/site x "
+                                 "sites / kernel time from HIP events over the %d timed launches; the kernel skips the "
+                                 "leaf-edge products through tip tables, so executed flops are about half of W_ll"
+                                 % (alg["W_ll"], kern_count),
                             hbm_model_equiv=hbm_model)
         else:
             roofline = dict(bound="hbm", achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
@@ -181,12 +249,14 @@ def main():
             "ll_sum": total,
             "roofline": roofline,
         }
+        if deriv_out is not None:
+            out["deriv"] = deriv_out
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_ll = cpu_baseline(wl, min(2 * S, 20_000_000), args.cpu_seconds)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

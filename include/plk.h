@@ -116,6 +116,17 @@ int plk_set_site_weights(plk_engine *h, const double *w, int where);
 int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out);
 
 /*
+ * The same evaluation queued on the engine's stream without waiting for it (optimisation loops, several GPUs):
+ * site_ll_dev (NULL or S doubles) and sum_dev (NULL or 2 doubles {hi, lo}) are DEVICE buffers of the caller; nothing is
+ * copied to the host.  plk_sync() -- or any synchronous call on the engine -- waits for the queued work.
+ * plk_set_stream() makes the engine issue its work on a HIP stream of the caller (hipStream_t passed as void *; NULL =
+ * the engine's own stream again), so that the caller's collectives and events are ordered with the engine's kernels.
+ */
+int plk_ll_async(plk_engine *h, double *site_ll_dev, double *sum_dev);
+int plk_sync(plk_engine *h);
+int plk_set_stream(plk_engine *h, void *hip_stream);
+
+/*
  * Edge-rate derivatives d ll_s / d edge_rate_coefficient_e (CSR edge order).
  * edge_mask: NULL (all) or E ints, nonzero = requested.
  * site_edge_out: NULL or [S][E] doubles, host; unrequested edges get 0.
@@ -191,7 +202,9 @@ enum {
     PLK_INFO_STACK_SLOTS = 1,     /* register-stack slots the tree needs */
     PLK_INFO_PROGRAM_OPS = 2,     /* ops in the traversal program */
     PLK_INFO_LAST_LL_KERNEL_NS = 3, /* HIP-event time of the last ll traversal kernel */
-    PLK_INFO_LAST_LL_TOTAL_NS = 4   /* HIP-event time of the last whole plk_ll device work */
+    PLK_INFO_LAST_LL_TOTAL_NS = 4,  /* HIP-event time of the last whole plk_ll device work */
+    PLK_INFO_LL_KERNEL_NS_SUM = 5,  /* HIP-event time of the traversal kernels of all ll evaluations since this item was */
+    PLK_INFO_LL_KERNEL_COUNT = 6    /* last read, and their number (reading waits for queued evaluations, then resets) */
 };
 
 /* force the generic (HBM-resident partials) traversal even where the fused

@@ -46,8 +46,15 @@
 
 struct plk_engine {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr;   /* stream in use; the engine's own one */
+    bool info_pending = false;           /* event times of the last ll evaluation not read yet */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    /* HIP-event pairs around the traversal kernel of the last PLK_EV_RING ll evaluations (read lazily, so that
+     * queued evaluations are not serialised by the measurement) */
+    hipEvent_t evk[64][2] = {};
+    bool evk_pending[64] = {};
+    int evk_next = 0;
+    long evk_sum_ns = 0, evk_count = 0;
     std::string err;
 
     /* tree */
@@ -78,7 +85,11 @@ struct plk_engine {
     double *d_w = nullptr;
 
     /* traversal program (plk_program.h) */
-    bool prog_dirty = true, stream_dirty = true;
+    /* prog_dirty: the program must be rebuilt (tree / patterns / options changed); fmt_dirty: its device formats are
+     * not uploaded for kernel kind fmt_kind; tables_dirty: the P-dependent tables (matrix stream, tip tables, A
+     * fragments) are older than P */
+    bool prog_dirty = true, fmt_dirty = true, tables_dirty = true;
+    long fmt_kind = 0;
     PlkProgram pg;
     std::vector<plk_op2> &ops = pg.ops;
     std::vector<int> &op_edge = pg.op_edge;          /* CSR edge per op or -1 */
@@ -91,7 +102,7 @@ struct plk_engine {
     int4 *d_fops = nullptr;              /* fused-kernel program (C++ interpreter) */
     unsigned *d_words = nullptr;         /* fused-kernel program (assembly interpreter) */
     std::vector<int> &mat_edge = fu.mat_edge;        /* CSR edge per compact matrix of the fused stream */
-    int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr;
+    int *d_op_edge = nullptr, *d_tip_edge = nullptr, *d_obs_nodes = nullptr, *d_mat_edge = nullptr, *d_edge_slot = nullptr;
     double *d_PS = nullptr;              /* [C][nops][K*K] transposed: PS[j*K+i] = P[i][j] */
     double *d_tip = nullptr;             /* [C][ntips][nchar][4] */
     double *d_frag = nullptr; size_t frag_cap = 0;   /* MFMA A fragments */
@@ -104,8 +115,9 @@ struct plk_engine {
     int *d_u4pack = nullptr;             /* k = 4 down / up passes: the call's integer tables, one block */
     double *d_u4tip = nullptr;           /* ... and its tip / edge-form tip tables */
     size_t u4pack_cap = 0, u4tip_cap = 0;
+    double *d_stage = nullptr; size_t stage_cap = 0;   /* transposed per-site outputs on their way to the host */
+    double *d_uvmat = nullptr; size_t uvmat_cap = 0;   /* vector down / up passes: PT and the up-pass matrix stream */
     int mfma_first_slot = -1, mfma_first_row = 0;
-    bool mfma_dirty = true;
     size_t ps_cap = 0, tip_cap = 0;
 
     /* workspaces */
@@ -210,6 +222,16 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
  * int_0^1 exp(s Qn u) L exp(s Qn (1-u)) du (src/util.c:501-548) -- is written to Fout, scaled by
  * coef = 1 (PLK_COEF_PRIOR), s (PLK_COEF_PRIOR_RATE_EDGE) or r_c (PLK_COEF_PRIOR_RATE).
  */
+/* k = 4, fused kernels: K1 also writes what the traversal reads, so that an evaluation with new edge rates is K1 + the
+ * traversal kernel + the reduction and nothing else: P_e (transposed) into its matrix of the stream for an internal
+ * edge, P_e * defs[code] (double-double, constant rows exact) into its tip slot for a leaf edge */
+struct ExpmPost {
+    const int *edge_slot;      /* [2][E]: matrix index of the edge or -1 | tip slot of the edge or -1; null: no post */
+    int nmat1, ntips1, nchar;  /* matrices / tip slots per category (incl. the spare / pseudo one), definitions */
+    const double *defs;        /* [nchar][4] */
+    double *PS, *tip;
+};
+
 template <bool FRECHET>
 __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *__restrict__ Qn /* [2][ks*ks]: hi then lo */,
                           const double *__restrict__ edge_rates,
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
                           dd *__restrict__ Pdd, double *__restrict__ P, double *__restrict__ dP,
                           dd *gscratch, int use_lds,
                           const double *__restrict__ Lm /* [2][ks*ks] */, int coef_mode,
-                          const int *__restrict__ edge_mask, double *__restrict__ Fout)
+                          const int *__restrict__ edge_mask, double *__restrict__ Fout, ExpmPost post)
 {
     extern __shared__ double smem_raw[];
     __shared__ double s_row[2 * PLK_MAX_K];
@@ -309,6 +331,32 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
         for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(O[l * k + j], dd_make(Qn[i * k + l], Qn[kk + i * k + l])));
         acc = dd_mul_d(acc, rc);
         dP[(size_t)ce * kk + idx] = acc.hi;
+    }
+    if (!FRECHET && post.edge_slot && k == 4) {
+        const int mi = post.edge_slot[e], t = post.edge_slot[E + e];
+        if (mi >= 0)
+            for (int idx = threadIdx.x; idx < 16; idx += blockDim.x) {
+                const int j = idx >> 2, i = idx & 3;
+                const double v = O[i * 4 + j].hi;
+                post.PS[((size_t)c * post.nmat1 + mi) * 16 + idx] = v < 0 ? 0.0 : v;
+            }
+        if (t >= 0)
+            for (int idx = threadIdx.x; idx < post.nchar * 4; idx += blockDim.x) {
+                const int code = idx >> 2, i = idx & 3;
+                const double *d = post.defs + code * 4;
+                double out;
+                if (d[0] == d[1] && d[0] == d[2] && d[0] == d[3]) out = d[0];      /* src/util.c:276-283 */
+                else {
+                    dd acc = dd_make(0.0, 0.0);
+                    for (int j = 0; j < 4; j++) {
+                        dd pij = O[i * 4 + j];
+                        if (pij.hi < 0) pij = dd_make(0.0, 0.0);
+                        acc = dd_add(acc, dd_mul_d(pij, d[j]));
+                    }
+                    out = acc.hi;
+                }
+                post.tip[(((size_t)c * post.ntips1 + t) * post.nchar + code) * 4 + i] = out;
+            }
     }
 }
 
@@ -422,6 +470,17 @@ __global__ void k_dd_final(int nblocks, const dd *__restrict__ partial, dd *__re
     if (threadIdx.x == 0) out[row] = r;
 }
 
+/* out[b] = sum of the b-th of gridDim.x contiguous slices of partial[0 .. n) */
+__global__ void k_dd_slices(int n, const dd *__restrict__ partial, dd *__restrict__ out)
+{
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    dd acc = dd_make(0.0, 0.0);
+    for (int b = lo + threadIdx.x; b < hi; b += blockDim.x) acc = dd_add(acc, partial[b]);
+    dd r = dd_block_sum(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
 /* partial[row][block] = sum_{s in block's range} w[s] * X[row][s] */
 __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ X,
                             const double *__restrict__ w, int nblocks, dd *__restrict__ partial)
@@ -445,6 +504,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_vec.h"
+#include "plk_updown_vec.h"
 #include "plk_updown4.h"
 
 /* ====================================================================== */
@@ -961,7 +1021,7 @@ extern "C" int plk_create(plk_engine **out, int device)
     }
     plk_engine *h = new plk_engine();
     h->device = device;
-    if (hipStreamCreate(&h->stream) != hipSuccess ||
+    if (hipStreamCreate(&h->own_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreate(&h->ev2) != hipSuccess || hipEventCreate(&h->ev3) != hipSuccess) {
         g_create_error = "plk_create: stream/event creation failed";
@@ -976,6 +1036,13 @@ extern "C" int plk_create(plk_engine **out, int device)
         }
         g_live.insert(h);
     }
+    h->stream = h->own_stream;
+    for (int i = 0; i < 64; i++)
+        if (hipEventCreate(&h->evk[i][0]) != hipSuccess || hipEventCreate(&h->evk[i][1]) != hipSuccess) {
+            g_create_error = "plk_create: event creation failed";
+            plk_destroy(h);
+            return PLK_E_DEVICE;
+        }
     *out = h;
     return PLK_OK;
 }
@@ -990,14 +1057,15 @@ extern "C" void plk_destroy(plk_engine *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
-                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
-                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_u4pack, h->d_u4tip, h->d_exL, h->d_exF, h->d_exmask, h->d_exscr, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+                    h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_edge_slot, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
+                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_u4pack, h->d_u4tip, h->d_uvmat, h->d_stage, h->d_exL, h->d_exF, h->d_exmask, h->d_exscr, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < 64; i++) for (int j = 0; j < 2; j++) if (h->evk[i][j]) (void)hipEventDestroy(h->evk[i][j]);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -1015,10 +1083,38 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     return PLK_E_ARG;
 }
 
+/* read the event pair of ring slot i (waits for it) into the running sum */
+static int evk_resolve(plk_engine *h, int i)
+{
+    if (!h->evk_pending[i]) return PLK_OK;
+    float ms = 0;
+    HIPCHK(h, hipEventSynchronize(h->evk[i][1]));
+    HIPCHK(h, hipEventElapsedTime(&ms, h->evk[i][0], h->evk[i][1]));
+    h->evk_pending[i] = false;
+    h->info_ll_kernel_ns = (long)(ms * 1e6);
+    h->evk_sum_ns += h->info_ll_kernel_ns;
+    h->evk_count++;
+    return PLK_OK;
+}
+
 extern "C" int plk_get_info(plk_engine *h, int what, long *out)
 {
     if (!plk_live(h) || !out) return PLK_E_ARG;
+    if (what >= PLK_INFO_LAST_LL_KERNEL_NS && what <= PLK_INFO_LL_KERNEL_COUNT) {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        for (int j = 0; j < 64; j++) if ((rc = evk_resolve(h, (h->evk_next + j) & 63))) return rc;     /* oldest first */
+        if (h->info_pending) {
+            float ms_t = 0;
+            HIPCHK(h, hipEventSynchronize(h->ev3));
+            HIPCHK(h, hipEventElapsedTime(&ms_t, h->ev0, h->ev3));
+            h->info_ll_total_ns = (long)(ms_t * 1e6);
+            h->info_pending = false;
+        }
+    }
     switch (what) {
+    case PLK_INFO_LL_KERNEL_NS_SUM: *out = h->evk_sum_ns; h->evk_sum_ns = 0; return PLK_OK;
+    case PLK_INFO_LL_KERNEL_COUNT: *out = h->evk_count; h->evk_count = 0; return PLK_OK;
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
     case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
@@ -1072,7 +1168,7 @@ extern "C" int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *
     return PLK_OK;
 }
 
-static int run_expm(plk_engine *h)
+static int run_expm(plk_engine *h, bool post = false)
 {
     const int k = h->k, C = h->C, E = h->E;
     const size_t kk = (size_t)k * k, n = (size_t)C * E * kk;
@@ -1085,12 +1181,18 @@ static int run_expm(plk_engine *h)
     if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * 4 * kk))) return rc; }
     /* one thread per few matrix entries: the dd matrix products are the whole cost for k = 61 */
     const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
+    ExpmPost ep = {};
+    post = post && k == 4 && h->fmt_kind == 1 && !h->fmt_dirty && h->d_edge_slot;
+    if (post) {
+        ep.edge_slot = h->d_edge_slot; ep.nmat1 = (int)h->mat_edge.size() + 1; ep.ntips1 = (int)h->tip_edge.size() + 1;
+        ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip;
+    }
     hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
-                       h->d_scratch, use_lds, (const double *)nullptr, 0, (const int *)nullptr, (double *)nullptr);
+                       h->d_scratch, use_lds, (const double *)nullptr, 0, (const int *)nullptr, (double *)nullptr, ep);
     HIPCHK(h, hipGetLastError());
     h->model_dirty = false;
-    h->stream_dirty = true;
+    h->tables_dirty = !post;
     return PLK_OK;
 }
 
@@ -1254,7 +1356,8 @@ static int build_program(plk_engine *h)
                                               h->node_has_data.data(), h->pg);
     if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     h->prog_dirty = false;
-    h->stream_dirty = true;
+    h->fmt_dirty = true;
+    h->tables_dirty = true;
     return PLK_OK;
 }
 
@@ -1293,66 +1396,99 @@ static bool use_fused(const plk_engine *h)
     return plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * fused_sites_per_lane(h)) <= PLK_LDS_LIMIT;
 }
 
-/* upload the program and (re)build the matrix stream / tip tables */
-static int prepare_stream(plk_engine *h, bool fused)
+/* Device formats of the program for kernel kind (1 fused k = 4, 2 generic, 3 matrix cores, 4 vector): uploaded when
+ * the program or the kind changes, not per evaluation. */
+static int upload_formats(plk_engine *h, long kind)
 {
     int rc;
-    const int nops = (int)h->ops.size();
-    const int K = h->K, C = h->C;
-    if (fused) {
-        if (!h->d_fops || h->stream_dirty) {
-            /* device formats of the program: int4 ops of the C++ interpreter, 32-bit op words of the assembly
-             * interpreter, compact matrix list (plk_program.h) */
-            plk_fused_build(h->N, h->pg, h->fu);
-            if ((rc = dev_upload(h, &h->d_fops, reinterpret_cast<const int4 *>(h->fu.fops.data()), h->fu.fops.size()))) return rc;
-            {
-                std::vector<int> me = h->mat_edge;
-                me.push_back(-1);                        /* the spare matrix is all zeros */
-                if ((rc = dev_upload(h, &h->d_mat_edge, me.data(), me.size()))) return rc;
+    const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
+    std::vector<int> te = h->tip_edge;
+    te.push_back(-1);                                /* pseudo slot: the raw definitions (internal nodes with data) */
+    if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
+    if (kind == 1) {
+        /* int4 ops of the C++ interpreter, 32-bit op words of the assembly interpreter, compact matrix list */
+        plk_fused_build(h->N, h->pg, h->fu);
+        if ((rc = dev_upload(h, &h->d_fops, reinterpret_cast<const int4 *>(h->fu.fops.data()), h->fu.fops.size()))) return rc;
+        if ((rc = dev_upload(h, &h->d_words, h->fu.words.data(), h->fu.words.size()))) return rc;
+        std::vector<int> me = h->mat_edge;
+        me.push_back(-1);                            /* the spare matrix is all zeros */
+        if ((rc = dev_upload(h, &h->d_mat_edge, me.data(), me.size()))) return rc;
+        /* where K1 itself puts P of edge e: its matrix of the stream (internal edges) or its tip slot (leaf edges) */
+        std::vector<int> em(2 * (size_t)h->E, -1);
+        for (size_t mi = 0; mi < h->mat_edge.size(); mi++) em[h->mat_edge[mi]] = (int)mi;
+        for (int t = 0; t < ntips; t++) em[(size_t)h->E + h->tip_edge[t]] = t;
+        if ((rc = dev_upload(h, &h->d_edge_slot, em.data(), em.size()))) return rc;
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * (h->mat_edge.size() + 1) * 16))) return rc;
+        if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4))) return rc;
+    } else {
+        /* OP_MATVEC ops name the next OP_MATVEC (y, wrapping to the first): the vector kernel touches the
+         * cache lines of the next matrix while it multiplies with the current one */
+        std::vector<plk_op2> gops(h->ops);
+        int first = -1, prev = -1;
+        for (int pc = 0; pc < nops; pc++)
+            if ((gops[pc].x & 0xff) == OP_MATVEC) {
+                if (first < 0) first = pc;
+                if (prev >= 0) gops[prev].y = pc;
+                prev = pc;
             }
-            {
-                /* tip slots + one pseudo slot (edge -1) holding the raw definitions, used for
-                 * internal nodes that carry data */
-                std::vector<int> te = h->tip_edge;
-                te.push_back(-1);
-                if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
-            }
-            if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
-            if ((rc = dev_upload(h, &h->d_words, h->fu.words.data(), h->fu.words.size()))) return rc;
+        if (prev >= 0) gops[prev].y = first;
+        if ((rc = dev_upload(h, &h->d_ops, reinterpret_cast<const int2 *>(gops.data()), gops.size()))) return rc;
+        if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * std::max(nops, 1) * h->K * h->K))) return rc;
+        if (kind == 4) {
+            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * h->K))) return rc;
+        } else if (kind == 3) {
+            const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
+            std::vector<double> rwd((size_t)4 * R, 0.0);
+            for (int i = 0; i < h->k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
+            if ((rc = dev_upload(h, &h->d_root_wd, rwd.data(), rwd.size()))) return rc;
+            if ((rc = dev_reserve(h, &h->d_frag, &h->frag_cap, (size_t)h->C * nops * T * kk4 * 64))) return rc;
+            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4 * R))) return rc;
+            /* MFMA program: observation ops name their staged code row and the next observation op */
+            PlkChain ch;
+            plk_chain_build(h->N, h->pg, 0, nullptr, nullptr, nullptr, nullptr, ch);
+            const std::string bad = plk_chain_check(h->N, h->pg, ch, 0, INT_MAX, 0, 0, 0, MF_SITES,
+                                                    (size_t)h->obs_nodes.size() * MF_SITES);
+            if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+            h->mfma_first_slot = ch.first_slot; h->mfma_first_row = ch.first_row;
+            if ((rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(ch.ops.data()), ch.ops.size()))) return rc;
         }
+    }
+    h->fmt_kind = kind;
+    h->fmt_dirty = false;
+    h->tables_dirty = true;
+    return PLK_OK;
+}
+
+/* P-dependent tables of kernel kind, from the current P (used when K1 ran without writing them itself) */
+static int build_tables(plk_engine *h, long kind)
+{
+    const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size(), K = h->K, C = h->C;
+    if (kind == 1) {
         const int nmat = (int)h->mat_edge.size();
         /* one spare matrix per category: the kernel always keeps the next matrix of the stream loaded */
-        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * (nmat + 1) * 16))) return rc;
         hipLaunchKernelGGL(k_build_stream, dim3(nmat + 1, C), dim3(64), 0, h->stream,
                            h->k, K, h->E, nmat + 1, h->d_mat_edge, h->d_P, h->d_PS);
-        HIPCHK(h, hipGetLastError());
-        const int ntips = (int)h->tip_edge.size() + 1;       /* + the pseudo slot of raw definitions */
-        if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)C * ntips * h->nchar * 4))) return rc;
-        hipLaunchKernelGGL(k_build_tip, dim3(ntips, C), dim3(64), 0, h->stream,
-                           h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
-        HIPCHK(h, hipGetLastError());
+        hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
+                           h->E, ntips + 1, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
     } else {
-        if (!h->d_ops || h->stream_dirty) {
-            /* OP_MATVEC ops name the next OP_MATVEC (y, wrapping to the first): the vector kernel touches the
-             * cache lines of the next matrix while it multiplies with the current one */
-            std::vector<plk_op2> gops(h->ops);
-            int first = -1, prev = -1;
-            for (int pc = 0; pc < nops; pc++)
-                if ((gops[pc].x & 0xff) == OP_MATVEC) {
-                    if (first < 0) first = pc;
-                    if (prev >= 0) gops[prev].y = pc;
-                    prev = pc;
-                }
-            if (prev >= 0) gops[prev].y = first;
-            if ((rc = dev_upload(h, &h->d_ops, reinterpret_cast<const int2 *>(gops.data()), gops.size()))) return rc;
-            if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
+        if (nops > 0)
+            hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
+                               h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
+        if (kind == 4) {
+            hipLaunchKernelGGL(k_build_tip_vec, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                               h->k, K, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+        } else if (kind == 3) {
+            const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
+            hipLaunchKernelGGL(k_build_frag, dim3(nops, C), dim3(256), 0, h->stream,
+                               h->k, T, kk4, h->E, nops, h->d_op_edge, h->d_P, h->d_frag);
+            hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                               h->k, R, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->K, h->d_tip);
         }
-        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)C * nops * K * K))) return rc;
-        hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
-                           h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
-        HIPCHK(h, hipGetLastError());
     }
-    h->stream_dirty = false;
+    HIPCHK(h, hipGetLastError());
+    h->tables_dirty = false;
     return PLK_OK;
 }
 
@@ -1368,24 +1504,24 @@ static void launch_generic(plk_engine *h, const GenArgs &a, unsigned grid)
     hipLaunchKernelGGL(k_ll_generic<K>, dim3(grid), dim3(GEN_BLOCK), 0, h->stream, a);
 }
 
-extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out)
+#define PLK_PARTIAL_OFF 72      /* d_partial: [0] the sum, [4, 68) second-stage inputs, [72, ...) one partial per workgroup */
+
+/* sum_dev != null: the {hi, lo} sum is left in device memory (2 doubles) and nothing is copied or waited for */
+static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_out, double *sum_dev, bool async)
 {
-    if (!plk_live(h)) return PLK_E_ARG;
     if (h->k == 0 || h->pat_mode == 0) { h->err = "plk_ll: tree, model and patterns must be set"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
     const bool fused = use_fused(h);
     /* trees with so many observed nodes that their staged code rows do not fit in LDS take the generic kernel */
     const bool vec = !fused && use_vec(h), mfma = !fused && !vec && use_mfma(h) && mfma_ll_lds_bytes(h) <= PLK_LDS_LIMIT;
     const long kind = fused ? 1 : (vec ? 4 : (mfma ? 3 : 2));
-    if (h->stream_dirty || kind != h->info_ll_kernel) {
-        h->stream_dirty = true;
-        h->mfma_dirty = true;
-        if ((rc = prepare_stream(h, fused))) return rc;
-    }
+    if (h->fmt_dirty || kind != h->fmt_kind) { if ((rc = upload_formats(h, kind))) return rc; }
+    if (h->model_dirty) { if ((rc = run_expm(h, true))) return rc; }      /* K1; for k = 4 it writes the stream and tip tables too */
+    if (h->tables_dirty) { if ((rc = build_tables(h, kind))) return rc; }
+    const bool want_sum = sum_out || sum_dev;
     const long S = h->S;
     double *d_out = nullptr;
     if (site_ll_out) {
@@ -1393,18 +1529,21 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         else { if ((rc = dev_reserve(h, &h->d_site_ll, &h->site_ll_cap, (size_t)S))) return rc; d_out = h->d_site_ll; }
     }
     unsigned grid;
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    const int evi = h->evk_next;
+    h->evk_next = (evi + 1) & 63;
+    if ((rc = evk_resolve(h, evi))) return rc;           /* only waits when 64 evaluations are queued */
+    HIPCHK(h, hipEventRecord(h->evk[evi][0], h->stream));
     if (fused) {
         const int NS = fused_sites_per_lane(h);
         grid = (unsigned)((S + PLK_TILE * NS - 1) / (PLK_TILE * NS));
-        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + PLK_PARTIAL_OFF))) return rc; }
         FusedArgs a;
         a.S = S; a.Spad = h->Spad; a.C = h->C; a.nops = (int)h->ops.size(); a.nmat = (int)h->mat_edge.size();
         a.ntips = (int)h->tip_edge.size() + 1; a.nchar = h->nchar; a.nobs = (int)h->obs_nodes.size();
         a.ops = h->d_fops; a.PS = h->d_PS; a.tip = h->d_tip;
         a.codes = h->d_codes; a.obs_nodes = h->d_obs_nodes; a.defs = h->d_defs;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w;
-        a.site_ll = d_out; a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        a.site_ll = d_out; a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         a.root_mode = h->root_mode; a.first_row = h->fu.first_row;
         const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
         const bool use_asm = NS == 1 && h->fu.asm_ok && h->opt_fused_asm;
@@ -1437,25 +1576,14 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         /* 9 <= k <= 32 with compact codes: register-resident vector kernel (plk_vec.h) */
         const int K = h->K, nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
         grid = (unsigned)((S + VEC_BLOCK - 1) / VEC_BLOCK);
-        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + PLK_PARTIAL_OFF))) return rc; }
         const int nslots = std::max(h->slots_needed, 1);
         if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * K * S))) return rc;
-        if (h->mfma_dirty) {
-            std::vector<int> te = h->tip_edge;
-            te.push_back(-1);
-            if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
-            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * K))) return rc;
-            hipLaunchKernelGGL(k_build_tip_vec, dim3(ntips + 1, h->C), dim3(256), 0, h->stream,
-                               h->k, K, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
-            HIPCHK(h, hipGetLastError());
-            h->mfma_dirty = false;
-        }
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         VecArgs a;
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.C = h->C; a.nops = nops; a.ntips = ntips; a.nchar = h->nchar;
         a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS; a.tip = h->d_tip; a.codes = h->d_codes;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
-        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         if (K == 16) hipLaunchKernelGGL(k_ll_vec<16>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         else if (K == 20) hipLaunchKernelGGL(k_ll_vec<20>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         else hipLaunchKernelGGL(k_ll_vec<32>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
@@ -1465,37 +1593,10 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
         const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
         grid = (unsigned)((S + MF_SITES - 1) / MF_SITES);
-        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + PLK_PARTIAL_OFF))) return rc; }
         const long slot_stride = (long)grid * MF_SITES * 4;
         const int nslots = std::max(h->slots_needed, 1);
         if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * R * slot_stride))) return rc;
-        if (h->mfma_dirty) {
-            std::vector<int> te = h->tip_edge;
-            te.push_back(-1);
-            if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
-            std::vector<double> rwd((size_t)4 * R, 0.0);
-            for (int i = 0; i < h->k; i++) rwd[(size_t)(i & 3) * R + (i >> 2)] = h->root_w[i];
-            if ((rc = dev_upload(h, &h->d_root_wd, rwd.data(), rwd.size()))) return rc;
-            if ((rc = dev_reserve(h, &h->d_frag, &h->frag_cap, (size_t)h->C * nops * T * kk4 * 64))) return rc;
-            if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4 * R))) return rc;
-            {   /* MFMA program: observation ops name their staged code row and the next observation op */
-                PlkChain ch;
-                plk_chain_build(h->N, h->pg, 0, nullptr, nullptr, nullptr, nullptr, ch);
-                const std::string bad = plk_chain_check(h->N, h->pg, ch, 0, INT_MAX, 0, 0, 0, MF_SITES,
-                                                        (size_t)h->obs_nodes.size() * MF_SITES);
-                if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
-                h->mfma_first_slot = ch.first_slot; h->mfma_first_row = ch.first_row;
-                if ((rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(ch.ops.data()), ch.ops.size()))) return rc;
-                if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
-            }
-            hipLaunchKernelGGL(k_build_frag, dim3(nops, h->C), dim3(256), 0, h->stream,
-                               h->k, T, kk4, h->E, nops, h->d_op_edge, h->d_P, h->d_frag);
-            hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, h->C), dim3(256), 0, h->stream,
-                               h->k, R, h->E, ntips, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->K, h->d_tip);
-            HIPCHK(h, hipGetLastError());
-            h->mfma_dirty = false;
-        }
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         MfmaArgs a;
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.kk4 = kk4; a.C = h->C; a.nops = nops; a.ntips = ntips;
         a.nchar = h->nchar; a.root_mode = h->root_mode; a.ops = h->d_mops; a.frag = h->d_frag; a.tip = h->d_tip;
@@ -1503,7 +1604,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
         a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
-        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         const size_t lds = mfma_ll_lds_bytes(h);
         if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
@@ -1512,7 +1613,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         h->info_ll_kernel = 3;
     } else {
         grid = (unsigned)((S + GEN_BLOCK - 1) / GEN_BLOCK);
-        if (sum_out) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + 4))) return rc; }
+        if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + PLK_PARTIAL_OFF))) return rc; }
         const int nslots = std::max(h->slots_needed, 1);
         if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * h->k * S))) return rc;
         GenArgs a;
@@ -1520,7 +1621,7 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         a.pat_mode = h->pat_mode; a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS;
         a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B; a.cat_prior = h->d_cat_prior;
         a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
-        a.partial = sum_out ? h->d_partial + 4 : nullptr;
+        a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         switch (h->K) {
         case 2: launch_generic<2>(h, a, grid); break;
         case 4: launch_generic<4>(h, a, grid); break;
@@ -1534,18 +1635,24 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
         h->info_ll_kernel = 2;
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev2, h->stream));
-    if (sum_out) {
-        hipLaunchKernelGGL(k_dd_final, dim3(1), dim3(256), 0, h->stream, (int)grid, h->d_partial + 4, h->d_partial);
+    HIPCHK(h, hipEventRecord(h->evk[evi][1], h->stream));
+    h->evk_pending[evi] = true;
+    if (want_sum) {
+        /* fixed-order double-double sum of the workgroups' partials: up to 64 slices, then one small block */
+        dd *out = sum_dev ? reinterpret_cast<dd *>(sum_dev) : h->d_partial;
+        const int g2 = grid > 1024 ? (int)std::min<unsigned>(64u, (grid + 511) / 512) : 1;
+        if (g2 > 1) {
+            hipLaunchKernelGGL(k_dd_slices, dim3(g2), dim3(256), 0, h->stream, (int)grid, h->d_partial + PLK_PARTIAL_OFF, h->d_partial + 4);
+            hipLaunchKernelGGL(k_dd_final, dim3(1), dim3(64), 0, h->stream, g2, h->d_partial + 4, out);
+        } else {
+            hipLaunchKernelGGL(k_dd_final, dim3(1), dim3(256), 0, h->stream, (int)grid, h->d_partial + PLK_PARTIAL_OFF, out);
+        }
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev3, h->stream));
+    h->info_pending = true;
+    if (async) return PLK_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms_k = 0, ms_t = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms_k, h->ev1, h->ev2));
-    HIPCHK(h, hipEventElapsedTime(&ms_t, h->ev0, h->ev3));
-    h->info_ll_kernel_ns = (long)(ms_k * 1e6);
-    h->info_ll_total_ns = (long)(ms_t * 1e6);
     if (sum_out) {
         dd r;
         HIPCHK(h, hipMemcpy(&r, h->d_partial, sizeof(dd), hipMemcpyDeviceToHost));
@@ -1553,6 +1660,39 @@ extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum
     }
     if (site_ll_out && where != PLK_DEVICE)
         HIPCHK(h, hipMemcpy(site_ll_out, h->d_site_ll, (size_t)S * sizeof(double), hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+extern "C" int plk_ll(plk_engine *h, double *site_ll_out, int where, double *sum_out)
+{
+    if (!plk_live(h)) return PLK_E_ARG;
+    return ll_impl(h, site_ll_out, where, sum_out, nullptr, false);
+}
+
+/* The same evaluation queued on the engine's stream without waiting: per-site values (optional) and the {hi, lo} sum
+ * (optional) are left in DEVICE memory the caller owns.  plk_sync() or any synchronous call waits for it. */
+extern "C" int plk_ll_async(plk_engine *h, double *site_ll_dev, double *sum_dev)
+{
+    if (!plk_live(h)) return PLK_E_ARG;
+    return ll_impl(h, site_ll_dev, PLK_DEVICE, nullptr, sum_dev, true);
+}
+
+extern "C" int plk_sync(plk_engine *h)
+{
+    if (!plk_live(h)) return PLK_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PLK_OK;
+}
+
+/* Run the engine's work on a stream of the caller (e.g. the framework's current stream, so that its collectives and
+ * events are ordered with the engine's kernels); NULL returns to the engine's own stream. */
+extern "C" int plk_set_stream(plk_engine *h, void *hip_stream)
+{
+    if (!plk_live(h)) return PLK_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return PLK_OK;
 }
 
@@ -1580,6 +1720,33 @@ static int wsum_rows(plk_engine *h, int rows, long n, const double *X, const dou
     HIPCHK(h, hipMemcpyAsync(host.data(), outp, rows * sizeof(dd), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int r = 0; r < rows; r++) acc[r] += (long double)host[r].hi + (long double)host[r].lo;
+    return PLK_OK;
+}
+
+/* per-site outputs leave the kernels as [row][site] planes (site fastest: coalesced stores); callers want
+ * [site][row].  Transposed on the device through LDS tiles, then one contiguous copy to the host. */
+__global__ __launch_bounds__(256) void k_transpose_rows(long rows, long n, const double *__restrict__ src, double *__restrict__ dst)
+{
+    __shared__ double tile[32][33];
+    const long r0 = (long)blockIdx.y * 32, s0 = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && s0 + tx < n) tile[j][tx] = src[(size_t)(r0 + j) * n + s0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (s0 + j < n && r0 + tx < rows) dst[(size_t)(s0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+static int copy_site_rows(plk_engine *h, size_t rows, long n, long s0, const double *d_src, double *site_out)
+{
+    if (rows == 0 || n == 0) return PLK_OK;
+    int rc;
+    if ((rc = dev_reserve(h, &h->d_stage, &h->stage_cap, rows * (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_transpose_rows, dim3((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, h->stream,
+                       (long)rows, n, d_src, h->d_stage);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(site_out + (size_t)s0 * rows, h->d_stage, rows * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return PLK_OK;
 }
 
@@ -1668,7 +1835,6 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
 
     std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
-    std::vector<double> stage;
     for (long s0 = 0; s0 < S; s0 += chunk) {
         const long n = std::min(chunk, S - s0);
         const unsigned grid = (unsigned)((n + MF_SITES - 1) / MF_SITES);
@@ -1708,15 +1874,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
             if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
             if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
-        if (site_out) {
-            const size_t rows = deriv ? (size_t)E : (size_t)N * k;
-            stage.resize(rows * (size_t)n);
-            hipError_t e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
-            for (size_t r = 0; r < rows; r++)
-                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
-        }
+        if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)E : (size_t)N * k, n, s0, deriv ? a.DV : a.MV, site_out))) { cleanup(); return rc; }
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     cleanup();
@@ -1829,7 +1987,6 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
 
     std::vector<long double> dsum(deriv ? ER : 0, 0.0L), msum(marg ? (size_t)N * 4 : 0, 0.0L);
-    std::vector<double> stage;
     for (long s0 = 0; s0 < S; s0 += chunk) {
         const long n = std::min(chunk, S - s0);
         Up4Args a;
@@ -1870,20 +2027,139 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
             if (deriv && E > 0 && (rc = wsum_rows(h, ER, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
             if (marg && (rc = wsum_rows(h, N * 4, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
-        if (site_out) {
-            const size_t rows = deriv ? (size_t)ER : (size_t)N * 4;
-            stage.resize(rows * (size_t)n);
-            hipError_t e = hipSuccess;
-            if (rows) e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
-            for (size_t r = 0; r < rows; r++)
-                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
-        }
+        if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)ER : (size_t)N * 4, n, s0, deriv ? a.DV : a.MV, site_out))) { cleanup(); return rc; }
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     cleanup();
     if (e != hipSuccess) { h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
+    if (sums_out) {
+        const std::vector<long double> &src = deriv ? dsum : msum;
+        for (size_t r = 0; r < src.size(); r++) {
+            const double hi = (double)src[r];
+            sums_out[2 * r] = hi;
+            sums_out[2 * r + 1] = (double)(src[r] - (long double)hi);
+        }
+    }
+    return PLK_OK;
+}
+
+/* deriv / marginal / edge expectations for 9 <= k <= 20 with compact codes: register-resident vector kernels
+ * (plk_updown_vec.h) */
+static bool use_updown_vec(const plk_engine *h)
+{
+    return !h->opt_force_generic && h->opt_mfma == 1 && h->pat_mode == 1 && h->k >= 9 && h->k <= 20 && h->E > 0;
+}
+
+template <int K>
+static void launch_updown_vec(plk_engine *h, const UpVecArgs &a, const int *d_obs, unsigned grid, bool deriv, bool marg)
+{
+    hipLaunchKernelGGL(k_down_vec<K>, dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a, d_obs);
+    if (deriv && marg) hipLaunchKernelGGL((k_up_vec<K, true, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+    else if (deriv) hipLaunchKernelGGL((k_up_vec<K, true, false>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_up_vec<K, false, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+}
+
+static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_mask, const int *node_mask,
+                          double *site_out, double *sums_out, const double *d_M, int dzero)
+{
+    int rc;
+    const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
+    const long S = h->S;
+    if (h->prog_dirty) { if ((rc = build_program(h))) return rc; }
+    const int ntips = (int)h->tip_edge.size();
+    std::vector<int> edge_tip(E, -1), edge_int(E, -1), node_int(N, -1), node_scale(N, -1);
+    for (int t = 0; t < ntips; t++) edge_tip[h->tip_edge[t]] = t;
+    int nie = 0, nin = 0, nsc = 0;
+    for (int e = 0; e < E; e++) if (edge_tip[e] < 0) edge_int[e] = nie++;
+    for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a]) node_int[a] = nin++;
+    for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
+    /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
+    PlkChain ch;
+    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
+    PlkUpVisits uv;
+    plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                        node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
+    {
+        std::string bad = plk_chain_check(N, h->pg, ch, 1, INT_MAX, nin, nie, nsc, 0, 0);
+        if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
+        if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+    }
+    const int nstream = (int)uv.kind.size();
+    const int nslots = std::max(h->slots_needed, 1);
+    std::vector<int> te = h->tip_edge;
+    te.push_back(-1);
+    /* integer tables of this call: one upload into the grow-only block */
+    std::vector<int> pack;
+    auto put = [&](const int *src, size_t n) { const size_t off = pack.size(); pack.insert(pack.end(), src, src + n); while (pack.size() % 4) pack.push_back(0); return off; };
+    const size_t o_ops = put(reinterpret_cast<const int *>(ch.ops.data()), ch.ops.size() * 4);
+    const size_t o_obs = put(h->obs_nodes.data(), h->obs_nodes.size());
+    const size_t o_vis = put(uv.rec.data(), uv.rec.size());
+    const size_t o_kind = put(uv.kind.data(), uv.kind.size()), o_edge = put(uv.edge.data(), uv.edge.size());
+    const size_t o_te = put(te.data(), te.size());
+    const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * K;
+    const size_t nmat = (size_t)C * E * K * K + (size_t)C * (nstream + 3) * K * K;
+    if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4)) ||
+        (rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, 2 * ntab)) ||
+        (rc = dev_reserve(h, &h->d_uvmat, &h->uvmat_cap, nmat))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_u4pack, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      /* pack is a local */
+    const int *b = h->d_u4pack;
+    double *d_PT = h->d_uvmat, *d_MS = h->d_uvmat + (size_t)C * E * K * K;
+    double *d_tipv = h->d_u4tip, *d_dtipv = h->d_u4tip + ntab;
+    const int bt = K * K >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_build_edge_stream, dim3(C * E), dim3(bt), 0, h->stream, k, K, 0, h->d_P, d_PT);
+    hipLaunchKernelGGL(k_build_up_stream, dim3(nstream + 3, C), dim3(bt), 0, h->stream, k, K, E, nstream, b + o_kind, b + o_edge,
+                       h->d_P, d_M, d_MS);
+    hipLaunchKernelGGL(k_build_tip_vec, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                       k, K, E, ntips, h->nchar, b + o_te, h->d_Pdd, h->d_defs, d_tipv);
+    hipLaunchKernelGGL(k_build_dtip_vec, dim3(ntips + 1, C), dim3(256), 0, h->stream,
+                       k, K, E, ntips, h->nchar, b + o_te, d_M, h->d_defs, K, d_dtipv, dzero);
+    if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
+
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * K + (size_t)nslots * K + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
+    budget += h->work_cap * sizeof(double);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
+    if (chunk < 1) { h->err = "plk_deriv/plk_marginal: not enough device memory for one site"; return PLK_E_NOMEM; }
+    if (chunk < S) chunk = std::max<long>(UDV_BLOCK, chunk / UDV_BLOCK * UDV_BLOCK);
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) return rc;
+
+    std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
+    for (long s0 = 0; s0 < S; s0 += chunk) {
+        const long n = std::min(chunk, S - s0);
+        UpVecArgs a;
+        a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
+        a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode; a.dzero = dzero;
+        a.ops = reinterpret_cast<const int4 *>(b + o_ops); a.nops = (int)h->ops.size(); a.root_int = node_int[h->preorder[0]];
+        a.PT = d_PT; a.tip = d_tipv; a.dtip = d_dtipv; a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w;
+        a.visits = b + o_vis; a.nvisits = uv.nvisits; a.MS = d_MS; a.nstream = nstream;
+        double *p = h->d_work;
+        a.LN = p; p += (size_t)nin * C * K * n;
+        a.FN = p; p += (size_t)nin * C * K * n;
+        a.slots = p; p += (size_t)nslots * K * n;
+        a.SC = p; p += (size_t)nsc * C * n;
+        a.CW = p; p += (size_t)C * n;
+        a.XC = p; p += (size_t)C * n;
+        a.LH = p; p += n;
+        a.DV = p; if (deriv) p += (size_t)E * n;
+        a.MV = p; if (marg) p += (size_t)N * k * n;
+        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
+        const unsigned grid = (unsigned)((n + UDV_BLOCK - 1) / UDV_BLOCK);
+        if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg);
+        else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg);
+        if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
+        if (sums_out) {
+            const double *w = h->d_w ? h->d_w + s0 : nullptr;
+            if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) return rc;
+            if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) return rc;
+        }
+        if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)E : (size_t)N * k, n, s0, deriv ? a.DV : a.MV, site_out))) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     if (sums_out) {
         const std::vector<long double> &src = deriv ? dsum : msum;
         for (size_t r = 0; r < src.size(); r++) {
@@ -1910,6 +2186,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
     const double *d_M = d_M_in ? d_M_in : h->d_dP;
+    if (use_updown_vec(h) && nM == 1) return run_updown_vec(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
     if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
     if (use_updown4(h)) return run_updown4(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero, nM);
     if (nM != 1) { h->err = "internal: several edge forms per pass need the k = 4 kernels"; return PLK_E_ARG; }
@@ -1957,7 +2234,6 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
 
     std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
-    std::vector<double> stage;
     for (long s0 = 0; s0 < S; s0 += chunk) {
         const long n = std::min(chunk, S - s0);
         UpArgs a;
@@ -1998,15 +2274,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
             if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
             if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
-        if (site_out) {
-            const size_t rows = deriv ? (size_t)E : (size_t)N * k;
-            stage.resize(rows * (size_t)n);
-            hipError_t e = hipMemcpyAsync(stage.data(), deriv ? a.DV : a.MV, rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { cleanup(); h->err = std::string("plk_deriv/plk_marginal: ") + hipGetErrorString(e); return PLK_E_DEVICE; }
-            for (size_t r = 0; r < rows; r++)
-                for (long s = 0; s < n; s++) site_out[(size_t)(s0 + s) * rows + r] = stage[r * (size_t)n + s];
-        }
+        if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)E : (size_t)N * k, n, s0, deriv ? a.DV : a.MV, site_out))) { cleanup(); return rc; }
     }
     hipError_t e = hipStreamSynchronize(h->stream);
     cleanup();
@@ -2076,7 +2344,7 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
         for (int m = 0; m < nm; m++) {
             hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                                k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
-                               d_scr, use_lds, d_L + (size_t)m * 2 * kk, coef_mode, d_mask, d_F + (size_t)m * C * E * kk);
+                               d_scr, use_lds, d_L + (size_t)m * 2 * kk, coef_mode, d_mask, d_F + (size_t)m * C * E * kk, ExpmPost{});
         }
         if (hipGetLastError() != hipSuccess) { h->err = "plk_edge_expect: Frechet kernel launch failed"; return PLK_E_DEVICE; }
         HIPCHK(h, hipStreamSynchronize(h->stream));          /* L is a host local */
@@ -2131,7 +2399,7 @@ extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const
     const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
     hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
-                       d_scr, use_lds, d_L, coef_mode, (const int *)nullptr, d_F);
+                       d_scr, use_lds, d_L, coef_mode, (const int *)nullptr, d_F, ExpmPost{});
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(F_out, d_F, (size_t)C * E * kk * sizeof(double), hipMemcpyDeviceToHost);
     cleanup();

@@ -429,8 +429,8 @@ struct PlkChain {
 };
 
 /* mode 0: MATVEC keeps (x, y) of the program (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
- * child node (k_down_fused4); mode 2: as 1 plus w = storage index of the edge (k_down_fused_mfma, no chain).
- * SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
+ * child node, w = CSR edge of the next MATVEC, wrapping to the first (k_down_fused4, k_down_vec); mode 2: as 1 but
+ * w = storage index of the edge (k_down_fused_mfma, no chain).  SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
 static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const int *indices, const int *node_int,
                                    const int *edge_int, const int *node_scale, PlkChain &ch)
 {
@@ -461,6 +461,132 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
         ch.ops[pc] = o;
     }
     if (prev >= 0) { ch.ops[prev].z = ch.first_slot | (1 << 30); ch.ops[prev].w = ch.first_row; }
+    if (mode == 1) {
+        int first_mv = -1, prev_mv = -1;
+        for (size_t pc = 0; pc < pg.ops.size(); pc++)
+            if ((pg.ops[pc].x & 0xff) == OP_MATVEC) {
+                if (first_mv < 0) first_mv = (int)pc;
+                if (prev_mv >= 0) ch.ops[prev_mv].w = pg.op_edge[pc];
+                prev_mv = (int)pc;
+            }
+        if (prev_mv >= 0) ch.ops[prev_mv].w = pg.op_edge[first_mv];
+    }
+}
+
+/*
+ * Up pass of the vector kernels (k_up_vec, plk_updown_vec.h): visit records of the internal nodes in BFS order and
+ * the list of matrices in the exact order the kernel consumes them (kind 0: P for a child message, 1: the edge-form
+ * matrix, 2: P for the forward vector of a child).  The builder and the kernel are the two halves of one contract;
+ * plk_up_visits_check() replays the kernel's consumption against the list.
+ *   header (8 ints): node, number of children, storage index of the node, rescaling slot or -1, has_data,
+ *                    first CSR edge, marginal of the root wanted (first record only), 0
+ *   child (4 ints):  node, tip slot or -1, PLK_UP_* flags, storage index (internal child) or -1
+ */
+enum { PLK_UP_WANT_D = 1, PLK_UP_WANT_F = 2, PLK_UP_WANT_M = 4, PLK_UP_STORE_F = 8 };
+
+struct PlkUpVisits {
+    std::vector<int> rec;
+    int nvisits = 0;
+    std::vector<int> kind, edge;       /* the matrix stream */
+};
+
+static inline void plk_up_visits_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
+                                       const int *edge_tip, const int *node_int, const int *node_scale, bool deriv, bool marg,
+                                       const int *edge_mask, const int *node_mask, PlkUpVisits &uv)
+{
+    uv.rec.clear(); uv.kind.clear(); uv.edge.clear(); uv.nvisits = 0;
+    auto flags = [&](int idx, int b) {
+        const bool leaf = edge_tip[idx] >= 0;
+        const bool wd = deriv && (!edge_mask || edge_mask[idx]);
+        const bool wm = marg && (!node_mask || node_mask[b]);
+        const bool wf = !leaf || wm;
+        return (wd ? PLK_UP_WANT_D : 0) | (wf ? PLK_UP_WANT_F : 0) | (wm ? PLK_UP_WANT_M : 0) | (!leaf ? PLK_UP_STORE_F : 0);
+    };
+    auto put = [&](int kind, int edge) { uv.kind.push_back(kind); uv.edge.push_back(edge); };
+    for (int u = 0; u < N; u++) {
+        const int a = preorder[u];
+        const int start = ip[a], deg = ip[a + 1] - start;
+        if (deg == 0) continue;
+        const int root_m = u == 0 && marg && (!node_mask || node_mask[a]);
+        const int hdr[8] = {a, deg, node_int[a], node_scale[a], node_has_data[a] ? 1 : 0, start, root_m, 0};
+        uv.rec.insert(uv.rec.end(), hdr, hdr + 8);
+        for (int j = 0; j < deg; j++) {
+            const int idx = start + j, b = ix[idx];
+            const int cr[4] = {b, edge_tip[idx], flags(idx, b), edge_tip[idx] >= 0 ? -1 : node_int[b]};
+            uv.rec.insert(uv.rec.end(), cr, cr + 4);
+        }
+        uv.nvisits++;
+        if (deg == 2) {
+            for (int j = 1; j >= 0; j--) {
+                const int idx = start + j;
+                if (edge_tip[idx] >= 0) continue;
+                put(0, idx);
+                if (flags(idx, ix[idx]) & PLK_UP_WANT_D) put(1, idx);
+            }
+            for (int j = 1; j >= 0; j--)
+                if (flags(start + j, ix[start + j]) & PLK_UP_WANT_F) put(2, start + j);
+        } else {
+            for (int j = 0; j < deg; j++) {
+                const int idx = start + j, fl = flags(idx, ix[idx]);
+                if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
+                for (int j2 = 0; j2 < deg; j2++)
+                    if (j2 != j && edge_tip[start + j2] < 0) put(0, start + j2);
+                if ((fl & PLK_UP_WANT_D) && edge_tip[idx] < 0) put(1, idx);
+                if (fl & PLK_UP_WANT_F) put(2, idx);
+            }
+        }
+    }
+}
+
+/* replays k_up_vec's walk over the records: every index in range, every stored forward vector written before it is
+ * read, and the matrices consumed are exactly the list, in order */
+static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &uv, int nint_nodes, int ntips, int nscale_slots,
+                                              bool deriv)
+{
+    std::vector<char> f_written(std::max(nint_nodes, 1), 0);
+    size_t vp = 0, ms = 0;
+    for (int v = 0; v < uv.nvisits; v++) {
+        if (vp + 8 > uv.rec.size()) return "up visits: record overrun";
+        const int *h = &uv.rec[vp];
+        const int a = h[0], deg = h[1], ai = h[2], slot = h[3], e0 = h[5];
+        if (a < 0 || a >= N || deg < 1 || ai < 0 || ai >= nint_nodes || slot < -1 || slot >= nscale_slots) return plk_fmt("up visits: bad header %ld", v);
+        if (e0 < 0 || e0 + deg > E) return plk_fmt("up visits: bad edge range in visit %ld", v);
+        if (vp + 8 + 4 * (size_t)deg > uv.rec.size()) return "up visits: record overrun";
+        if (v == 0) f_written[ai] = 1;       /* the root's forward vector is written first */
+        if (!f_written[ai]) return plk_fmt("up visits: forward vector of node %ld read before it is written", a);
+        const int *ch = h + 8;
+        auto need = [&](int kind, int edge) -> bool { const bool ok = ms < uv.kind.size() && uv.kind[ms] == kind && uv.edge[ms] == edge; ms++; return ok; };
+        for (int j = 0; j < deg; j++) {
+            const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
+            if (b < 0 || b >= N || t < -1 || t >= ntips || (t < 0 && (bi < 0 || bi >= nint_nodes))) return plk_fmt("up visits: bad child in visit %ld", v);
+            if (((fl & PLK_UP_STORE_F) != 0) != (t < 0) || (t < 0 && !(fl & PLK_UP_WANT_F))) return plk_fmt("up visits: flags of an internal child in visit %ld", v);
+            if (!deriv && (fl & PLK_UP_WANT_D)) return "up visits: derivative flag without a derivative pass";
+        }
+        if (deg == 2) {
+            for (int j = 1; j >= 0; j--)
+                if (ch[4 * j + 1] < 0) {
+                    if (!need(0, e0 + j)) return plk_fmt("up visits: stream mismatch (message) in visit %ld", v);
+                    if ((ch[4 * j + 2] & PLK_UP_WANT_D) && !need(1, e0 + j)) return plk_fmt("up visits: stream mismatch (edge form) in visit %ld", v);
+                }
+            for (int j = 1; j >= 0; j--)
+                if ((ch[4 * j + 2] & PLK_UP_WANT_F) && !need(2, e0 + j)) return plk_fmt("up visits: stream mismatch (forward) in visit %ld", v);
+        } else {
+            for (int j = 0; j < deg; j++) {
+                const int fl = ch[4 * j + 2];
+                if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
+                for (int j2 = 0; j2 < deg; j2++)
+                    if (j2 != j && ch[4 * j2 + 1] < 0 && !need(0, e0 + j2)) return plk_fmt("up visits: stream mismatch (sibling) in visit %ld", v);
+                if ((fl & PLK_UP_WANT_D) && ch[4 * j + 1] < 0 && !need(1, e0 + j)) return plk_fmt("up visits: stream mismatch (edge form) in visit %ld", v);
+                if ((fl & PLK_UP_WANT_F) && !need(2, e0 + j)) return plk_fmt("up visits: stream mismatch (forward) in visit %ld", v);
+            }
+        }
+        for (int j = 0; j < deg; j++) if (ch[4 * j + 2] & PLK_UP_STORE_F) f_written[ch[4 * j + 3]] = 1;
+        vp += 8 + 4 * (size_t)deg;
+    }
+    if (vp != uv.rec.size()) return "up visits: trailing records";
+    if (ms != uv.kind.size()) return "up visits: matrix stream not consumed";
+    for (size_t i = 0; i < uv.edge.size(); i++) if (uv.edge[i] < 0 || uv.edge[i] >= E || uv.kind[i] < 0 || uv.kind[i] > 2) return "up visits: bad stream entry";
+    return "";
 }
 
 static inline std::string plk_chain_check(int N, const PlkProgram &pg, const PlkChain &ch, int mode, int D, int nint_nodes,

@@ -1,0 +1,510 @@
+/*
+ * plk_updown_vec.h -- down pass with stored vectors and BFS-order up pass for medium state spaces
+ * (9 <= k <= 20: amino acids) on the vector fp64 pipe: arbplf-deriv / -marginal / -dwell / -trans / -em-update
+ * at K = 16 and K = 20.  Included by plk_engine.hip.
+ *
+ * Same formulas as k_down_store / k_up (src/evaluate_site_lhood.c:7-63 with node vectors kept,
+ * src/evaluate_site_forward.c:32-105, src/arbplfderiv.c:112-207,:312-342, src/evaluate_site_marginal.c:7-21,
+ * src/arbplfmarginal.c:206-234, src/evaluate_site_frechet.c:5-42).  Round 1 ran these state counts on the
+ * matrix cores in the 4-lanes-per-site layout: k = 20 was padded to two 16-row tiles (2.56x the matrix work) and
+ * every stored vector to 32 doubles (1.6x the traffic), 0.28 of the HBM roof at BASELINE config 4.  Here:
+ *   - one site per lane, a vector in K VGPR pairs, P_e / M_e / P_e^T as scalar-loaded SGPR operands of v_fma_f64
+ *     (k^2 FMAs per product, no padding, no LDS, no barriers) -- the k_ll_vec design;
+ *   - stored vectors un-padded, one plane per state: [entity][category][state][site], 512 contiguous bytes per
+ *     wavefront access; only internal node vectors L_a and forward vectors F_a are stored, edge vectors
+ *     P_e L_b are recomputed in the up pass from the L_b the edge form needs anyway;
+ *   - down pass = depth-first traversal of the post-order program: every L_a is written once, at the product that
+ *     consumes it; vectors waiting for a sibling subtree go to HBM stack slots (they come back from L2 /
+ *     Infinity Cache);
+ *   - up pass: the two children of a node are handled in one visit (F_a, L_b0, L_b1 read once; the products
+ *     P_e L_b and M_e L_b share their input), leaf edges gather P_e B_b and M_e B_b from double-double built tables;
+ *   - the matrices of the up pass are laid out as a stream in the exact order of use (built per query), so the
+ *     64-byte lines of the next product's matrix are requested through the scalar cache while the current product
+ *     runs (vec_touch of plk_vec.h: waited for inside the asm statement);
+ *   - exact power-of-two rescaling with stored factors, categories combined at a common exponent (as k_up4).
+ */
+#ifndef PLK_UPDOWN_VEC_H
+#define PLK_UPDOWN_VEC_H
+
+#define UDV_BLOCK 128
+
+struct UpVecArgs {
+    long S, Spad, s0, n;
+    int N, E, k, C, nchar, ntips, root_mode;
+    int dzero;                     /* 1: edge-form matrices have zero row sums (dP) */
+    /* down pass: program (int4: observation y = node; MATVEC y = CSR edge, z = storage index of the child node,
+     * w = CSR edge of the next MATVEC (wrapping); PUSH / POPMUL y = slot; SCALE y = rescaling slot or -1) */
+    const int4 *ops;
+    int nops, root_int;
+    const double *PT;              /* [C][E][K*K] transposed P: PT[j*K+i] = P[i][j] (down pass) */
+    const double *tip, *dtip;      /* [C][ntips+1][nchar][K]: P_e defs (slot ntips: defs themselves); M_e defs */
+    const uint8_t *codes;
+    const double *cat_prior, *root_w;
+    /* up pass: visit records and the matrix stream in order of use */
+    const int *visits;             /* plk_up_visits_build() of plk_program.h */
+    int nvisits;
+    const double *MS;              /* [C][nstream + 3][K*K] */
+    int nstream;
+    double *LN, *FN;               /* [(ent*C + c)][K][n] */
+    double *slots;                 /* [slot][K][n] */
+    double *SC, *CW, *XC;          /* as Up4Args */
+    double *LH, *DV, *MV;          /* [n], [E][n], [N][k][n] */
+};
+
+/* child record of a visit: 4 ints */
+#define UDV_WANT_D PLK_UP_WANT_D
+#define UDV_WANT_F PLK_UP_WANT_F   /* forward vector of the child is needed (internal child, or its marginal) */
+#define UDV_WANT_M PLK_UP_WANT_M
+#define UDV_STORE_F PLK_UP_STORE_F /* internal child: F_b is stored */
+
+template <int K>
+__device__ __forceinline__ void udv_load(const double *base, size_t n, long slc, double (&out)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) out[i] = base[(size_t)i * n + slc];
+}
+template <int K>
+__device__ __forceinline__ void udv_store(double *base, size_t n, long slc, const double (&v)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) base[(size_t)i * n + slc] = v[i];
+}
+template <int K>
+__device__ __forceinline__ void udv_gather(const double *row, double (&out)[K])
+{
+    const double2 *tp = reinterpret_cast<const double2 *>(row);
+#pragma unroll
+    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; out[i] = v.x; out[i + 1] = v.y; }
+}
+template <int K>
+__device__ __forceinline__ bool udv_const(const double (&x)[K], int k)
+{
+    bool c = true;
+#pragma unroll
+    for (int i = 1; i < K; i++) c = c && (i >= k || x[i] == x[0]);
+    return c;
+}
+/* acc = M x, M[j*K + i] multiplies x[j] into acc[i] (uniform pointer: SGPR operands) */
+template <int K>
+__device__ __forceinline__ void udv_matvec(const PLK_AS4 double *M, const double (&x)[K], double (&acc)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) acc[i] = M[i] * x[0];
+#pragma unroll
+    for (int j = 1; j < K; j++) {
+#pragma unroll
+        for (int i = 0; i < K; i++) acc[i] = fma(M[j * K + i], x[j], acc[i]);
+    }
+}
+/* two products that share their input */
+template <int K>
+__device__ __forceinline__ void udv_matvec2(const PLK_AS4 double *M1, const PLK_AS4 double *M2, const double (&x)[K],
+                                            double (&a1)[K], double (&a2)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) { a1[i] = M1[i] * x[0]; a2[i] = M2[i] * x[0]; }
+#pragma unroll
+    for (int j = 1; j < K; j++) {
+#pragma unroll
+        for (int i = 0; i < K; i++) { a1[i] = fma(M1[j * K + i], x[j], a1[i]); a2[i] = fma(M2[j * K + i], x[j], a2[i]); }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+template <int K>
+__global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *__restrict__ obs_nodes)
+{
+    const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const size_t n = (size_t)a.n;
+    const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(a.ops));
+    const PLK_AS4 int *obs = as_uniform(obs_nodes);
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
+    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
+    int xmax = INT_MIN;
+    for (int c = 0; c < a.C; c++) {
+        double cur[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) cur[i] = 1.0;
+        int X = 0;
+        const PLK_AS4 double *PTc = as_uniform(a.PT) + (size_t)c * a.E * K * K;
+        const double *tipc = a.tip + (size_t)c * tabc;
+        for (int pc = 0; pc < a.nops; pc++) {
+            const int ox = ops[4 * pc], oy = ops[4 * pc + 1];
+            const int code = ox & 0xff;
+            if (code == OP_MATVEC) {
+                const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
+                /* the child's vector is final: store it, then multiply by its edge's P */
+                if (valid) udv_store<K>(a.LN + ((size_t)oz * a.C + c) * K * n, n, slc, cur);
+                vec_touch<K>(PTc + (size_t)ow * K * K);            /* lines of the next product's matrix */
+                const bool cst = udv_const<K>(cur, a.k);
+                const double x0 = cur[0];
+                double acc[K];
+                udv_matvec<K>(PTc + (size_t)oy * K * K, cur, acc);
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] = cst ? (i < a.k ? x0 : 0.0) : acc[i];   /* src/util.c:276-283 */
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
+                const int ch = a.codes[(size_t)obs[oy] * a.Spad + sg];
+                double v[K];
+                udv_gather<K>(tipc + ((size_t)t * a.nchar + ch) * K, v);
+                if (code == OP_TIP_SET) {
+#pragma unroll
+                    for (int i = 0; i < K; i++) cur[i] = v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < K; i++) cur[i] *= v[i];
+                }
+            } else if (code == OP_PUSH) {
+                if (valid) udv_store<K>(a.slots + (size_t)oy * K * n, n, slc, cur);
+            } else if (code == OP_POPMUL) {
+                double v[K];
+                udv_load<K>(a.slots + (size_t)oy * K * n, n, slc, v);
+#pragma unroll
+                for (int i = 0; i < K; i++) cur[i] *= v[i];
+            } else if (code == OP_SCALE) {
+                if (oy >= 0) {
+                    double mx = 0.0;
+#pragma unroll
+                    for (int i = 0; i < K; i++) mx = fmax(mx, cur[i]);
+                    double sc = 1.0;
+                    if (mx > 0x1p-1000 && mx < 0x1p+1000) {
+                        const int ex = ilogb(mx);
+                        sc = ldexp(1.0, -ex);
+#pragma unroll
+                        for (int i = 0; i < K; i++) cur[i] *= sc;
+                        X += ex;
+                    }
+                    if (valid) a.SC[((size_t)oy * a.C + c) * n + slc] = sc;
+                }
+            }
+        }
+        if (valid) udv_store<K>(a.LN + ((size_t)a.root_int * a.C + c) * K * n, n, slc, cur);
+        double lh_c = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; i++) lh_c = fma(rw[i], cur[i], lh_c);        /* root_w is zero padded; NONE -> ones, UNIFORM -> 1/k */
+        lh_c *= prior[c];
+        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (valid) { a.XC[(size_t)c * n + slc] = (double)X; a.CW[(size_t)c * n + slc] = lh_c; }
+    }
+    if (xmax == INT_MIN) xmax = 0;
+    if (valid) {
+        double lh_total = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + slc] - xmax);
+            lh_total = fma(a.CW[(size_t)c * n + slc], w, lh_total);
+            a.CW[(size_t)c * n + slc] = w;
+        }
+        a.LH[sl] = lh_total;
+    }
+}
+
+/*
+ * Up pass.  visits: for every internal node in BFS order
+ *   header (8 ints): node a, number of children, storage index of a, rescaling slot or -1, has_data, 0, 0, 0
+ *   per child (4 ints): child node b, tip slot or -1, UDV_* flags, storage index of b (internal) or -1;
+ *   children with a CSR edge index idx = first_edge + position: the header's int [5] holds first_edge.
+ * Matrix stream MS (per category): the matrices in the order the visit code below consumes them:
+ *   two children:  for j = 1, 0: internal child j: P_ej^T-layout (PT) [+ M_ej (DT) if WANT_D];  then for j = 1, 0:
+ *                  if WANT_F: plain P_ej (PN)
+ *   otherwise:     per child in order: for every internal sibling PT(sibling); internal child with WANT_D: DT;
+ *                  WANT_F: PN
+ * (the host builder plk_up_visits_build() and this kernel are the two halves of that contract; the stream always has one
+ * spare matrix at the end for the look-ahead)
+ */
+template <int K, bool DERIV, bool MARG>
+__global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
+{
+    const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const long sg = a.s0 + slc;
+    const size_t n = (size_t)a.n;
+    const PLK_AS4 int *vis = as_uniform(a.visits);
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
+    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
+    const double inv = 1.0 / a.LH[slc];
+    constexpr int KK = K * K;
+
+    {   /* root: forward vector = root prior weights; its marginal */
+        const int root = vis[0], root_int = vis[2];
+        double macc[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) macc[i] = 0.0;
+        for (int c = 0; c < a.C; c++) {
+            double f[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) f[i] = rw[i];
+            if (valid) udv_store<K>(a.FN + ((size_t)root_int * a.C + c) * K * n, n, slc, f);
+            if (MARG) {
+                double l[K];
+                udv_load<K>(a.LN + ((size_t)root_int * a.C + c) * K * n, n, slc, l);
+                const double pc = prior[c] * a.CW[(size_t)c * n + slc];
+#pragma unroll
+                for (int i = 0; i < K; i++) macc[i] = fma(pc * f[i], l[i], macc[i]);
+            }
+        }
+        if (MARG && valid && vis[6]) {
+#pragma unroll
+            for (int i = 0; i < K; i++)
+                if (i < a.k) a.MV[((size_t)root * a.k + i) * n + sl] = macc[i] * inv;
+        }
+    }
+
+    for (int c = 0; c < a.C; c++) {
+        const double *tipc = a.tip + (size_t)c * tabc;
+        const double *dtipc = a.dtip + (size_t)c * tabc;
+        /* every product requests the lines of the matrix (or pair) two slots ahead: each slot is touched once, one or
+         * two products before its use; three spare slots at the end of the stream */
+        const PLK_AS4 double *ms = as_uniform(a.MS) + (size_t)c * (a.nstream + 3) * KK;
+        const double pc = prior[c] * a.CW[(size_t)c * n + slc];
+        const bool first_cat = c == 0, last_cat = c == a.C - 1;
+        int vp = 0;
+        for (int v = 0; v < a.nvisits; v++) {
+            const int nd = vis[vp], deg = vis[vp + 1], nd_int = vis[vp + 2], slot = vis[vp + 3], hd = vis[vp + 4], e0 = vis[vp + 5];
+            const PLK_AS4 int *ch = vis + vp + 8;
+            vp += 8 + 4 * deg;
+            /* forward vector of the node, with its own observation and its rescaling factor folded in */
+            double F[K];
+            udv_load<K>(a.FN + ((size_t)nd_int * a.C + c) * K * n, n, slc, F);
+            if (hd) {
+                double bv[K];
+                udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * K, bv);
+#pragma unroll
+                for (int i = 0; i < K; i++) F[i] *= bv[i];
+            }
+            if (slot >= 0) {
+                const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+#pragma unroll
+                for (int i = 0; i < K; i++) F[i] *= sc;
+            }
+            /* accumulate over categories in the output planes: first category writes, later ones add */
+#define UDV_OUT_D(EDGE, VAL)                                                                              \
+            do { if (valid) { double *dp_ = a.DV + (size_t)(EDGE) * n + sl;                               \
+                 const double t_ = (VAL); *dp_ = (first_cat ? t_ : *dp_ + t_) * (last_cat ? inv : 1.0); } } while (0)
+#define UDV_OUT_M(NODE, FB, LB)                                                                           \
+            do { if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {                \
+                 double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
+                 const double t_ = pc * FB[i] * LB[i]; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
+
+            if (deg == 2) {
+                const int b0 = ch[0], t0 = ch[1], f0 = ch[2], i0 = ch[3];
+                const int b1 = ch[4], t1 = ch[5], f1 = ch[6], i1 = ch[7];
+                double m0[K], y0[K], m1[K], y1[K];
+                /* child 1, then child 0: message m = P L (or table), edge-form vector y = M L (or table) */
+                if (t1 >= 0) {
+                    const int cd = a.codes[(size_t)b1 * a.Spad + sg];
+                    udv_gather<K>(tipc + ((size_t)t1 * a.nchar + cd) * K, m1);
+                    if (DERIV && (f1 & UDV_WANT_D)) udv_gather<K>(dtipc + ((size_t)t1 * a.nchar + cd) * K, y1);
+                } else {
+                    double L[K];
+                    udv_load<K>(a.LN + ((size_t)i1 * a.C + c) * K * n, n, slc, L);
+                    const bool cst = udv_const<K>(L, a.k);
+                    if (DERIV && (f1 & UDV_WANT_D)) {
+                        vec_touch<K>(ms + 2 * KK); vec_touch<K>(ms + 3 * KK);
+                        udv_matvec2<K>(ms, ms + KK, L, m1, y1);
+                        ms += 2 * KK;
+                        if (a.dzero && cst) {
+#pragma unroll
+                            for (int i = 0; i < K; i++) y1[i] = 0.0;
+                        }
+                    } else {
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, L, m1);
+                        ms += KK;
+                    }
+                    if (cst) {
+#pragma unroll
+                        for (int i = 0; i < K; i++) m1[i] = i < a.k ? L[0] : 0.0;
+                    }
+                }
+                if (t0 >= 0) {
+                    const int cd = a.codes[(size_t)b0 * a.Spad + sg];
+                    udv_gather<K>(tipc + ((size_t)t0 * a.nchar + cd) * K, m0);
+                    if (DERIV && (f0 & UDV_WANT_D)) udv_gather<K>(dtipc + ((size_t)t0 * a.nchar + cd) * K, y0);
+                } else {
+                    double L[K];
+                    udv_load<K>(a.LN + ((size_t)i0 * a.C + c) * K * n, n, slc, L);
+                    const bool cst = udv_const<K>(L, a.k);
+                    if (DERIV && (f0 & UDV_WANT_D)) {
+                        vec_touch<K>(ms + 2 * KK); vec_touch<K>(ms + 3 * KK);
+                        udv_matvec2<K>(ms, ms + KK, L, m0, y0);
+                        ms += 2 * KK;
+                        if (a.dzero && cst) {
+#pragma unroll
+                            for (int i = 0; i < K; i++) y0[i] = 0.0;
+                        }
+                    } else {
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, L, m0);
+                        ms += KK;
+                    }
+                    if (cst) {
+#pragma unroll
+                        for (int i = 0; i < K; i++) m0[i] = i < a.k ? L[0] : 0.0;
+                    }
+                }
+                /* child 1: fe1 = F o m0 */
+                {
+                    double fe[K];
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] = F[i] * m0[i];
+                    if (DERIV && (f1 & UDV_WANT_D)) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int i = 0; i < K; i++) d = fma(fe[i], y1[i], d);
+                        UDV_OUT_D(e0 + 1, pc * d);
+                    }
+                    if (f1 & UDV_WANT_F) {
+                        double fb[K];
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, fe, fb);
+                        ms += KK;
+                        if ((f1 & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)i1 * a.C + c) * K * n, n, slc, fb);
+                        if (MARG && (f1 & UDV_WANT_M)) {
+                            double lb[K];
+                            if (t1 >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b1 * a.Spad + sg]) * K, lb);
+                            else udv_load<K>(a.LN + ((size_t)i1 * a.C + c) * K * n, n, slc, lb);
+                            UDV_OUT_M(b1, fb, lb);
+                        }
+                    }
+                }
+                /* child 0: fe0 = F o m1 */
+                {
+                    double fe[K];
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] = F[i] * m1[i];
+                    if (DERIV && (f0 & UDV_WANT_D)) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int i = 0; i < K; i++) d = fma(fe[i], y0[i], d);
+                        UDV_OUT_D(e0, pc * d);
+                    }
+                    if (f0 & UDV_WANT_F) {
+                        double fb[K];
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, fe, fb);
+                        ms += KK;
+                        if ((f0 & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)i0 * a.C + c) * K * n, n, slc, fb);
+                        if (MARG && (f0 & UDV_WANT_M)) {
+                            double lb[K];
+                            if (t0 >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b0 * a.Spad + sg]) * K, lb);
+                            else udv_load<K>(a.LN + ((size_t)i0 * a.C + c) * K * n, n, slc, lb);
+                            UDV_OUT_M(b0, fb, lb);
+                        }
+                    }
+                }
+                continue;
+            }
+            /* one child, or three and more (e.g. the root of an unrooted tree): one edge at a time, sibling messages
+             * recomputed for every edge */
+            for (int j = 0; j < deg; j++) {
+                const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
+                if (!(fl & (UDV_WANT_D | UDV_WANT_F))) continue;
+                double fe[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) fe[i] = F[i];
+                for (int j2 = 0; j2 < deg; j2++) {
+                    if (j2 == j) continue;
+                    const int b2 = ch[4 * j2], t2 = ch[4 * j2 + 1], bi2 = ch[4 * j2 + 3];
+                    double m[K];
+                    if (t2 >= 0) udv_gather<K>(tipc + ((size_t)t2 * a.nchar + a.codes[(size_t)b2 * a.Spad + sg]) * K, m);
+                    else {
+                        double L[K];
+                        udv_load<K>(a.LN + ((size_t)bi2 * a.C + c) * K * n, n, slc, L);
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, L, m);
+                        ms += KK;
+                        if (udv_const<K>(L, a.k)) {
+#pragma unroll
+                            for (int i = 0; i < K; i++) m[i] = i < a.k ? L[0] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] *= m[i];
+                }
+                if (DERIV && (fl & UDV_WANT_D)) {
+                    double y[K];
+                    if (t >= 0) udv_gather<K>(dtipc + ((size_t)t * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, y);
+                    else {
+                        double L[K];
+                        udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, L);
+                        vec_touch<K>(ms + 2 * KK);
+                        udv_matvec<K>(ms, L, y);
+                        ms += KK;
+                        if (a.dzero && udv_const<K>(L, a.k)) {
+#pragma unroll
+                            for (int i = 0; i < K; i++) y[i] = 0.0;
+                        }
+                    }
+                    double d = 0.0;
+#pragma unroll
+                    for (int i = 0; i < K; i++) d = fma(fe[i], y[i], d);
+                    UDV_OUT_D(e0 + j, pc * d);
+                }
+                if (fl & UDV_WANT_F) {
+                    double fb[K];
+                    vec_touch<K>(ms + 2 * KK);
+                    udv_matvec<K>(ms, fe, fb);
+                    ms += KK;
+                    if ((fl & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)bi * a.C + c) * K * n, n, slc, fb);
+                    if (MARG && (fl & UDV_WANT_M)) {
+                        double lb[K];
+                        if (t >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, lb);
+                        else udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, lb);
+                        UDV_OUT_M(b, fb, lb);
+                    }
+                }
+            }
+        }
+#undef UDV_OUT_D
+#undef UDV_OUT_M
+    }
+}
+
+/* dtip[((c*(ntips+1) + t)*nchar + code)*K + i] = (M_e defs[code])[i] in double-double; zero for constant definition
+ * rows when the matrices have zero row sums (src/util.c:338-345); slot ntips unused (zeros) */
+__global__ void k_build_dtip_vec(int k, int K, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
+                                 const double *__restrict__ M /* [C][E][k][k] */, const double *__restrict__ defs /* [nchar][Kdef] */,
+                                 int Kdef, double *__restrict__ dtip, int dzero)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int e = tip_edge[t];
+    for (int idx = threadIdx.x; idx < nchar * K; idx += blockDim.x) {
+        const int code = idx / K, i = idx - code * K;
+        const double *d = defs + (size_t)code * Kdef;
+        double out = 0.0;
+        if (i < k && e >= 0) {
+            bool constant = true;
+            for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
+            if (!(constant && dzero)) {
+                const double *row = M + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                dd acc = dd_make(0.0, 0.0);
+                for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
+                out = acc.hi;
+            }
+        }
+        dtip[(((size_t)c * (ntips + 1) + t) * nchar + code) * K + i] = out;
+    }
+}
+
+/* matrix stream of the up pass: MS[c][slot] = matrix kind[slot] of edge edge[slot]; kind 0: transposed P (PT layout:
+ * out[j*K+i] = P[i][j]), 1: transposed M (edge form), 2: plain P (out[i*K+j] = P[i][j]); slots nstream .. nstream+2: zeros */
+__global__ void k_build_up_stream(int k, int K, int E, int nstream, const int *__restrict__ kind, const int *__restrict__ edge,
+                                  const double *__restrict__ P, const double *__restrict__ M, double *__restrict__ MS)
+{
+    const int slot = blockIdx.x, c = blockIdx.y;
+    double *dst = MS + ((size_t)c * (nstream + 3) + slot) * K * K;
+    const int kd = slot < nstream ? kind[slot] : -1;
+    const double *src = kd < 0 ? nullptr : (kd == 1 ? M : P) + ((size_t)c * E + edge[slot < nstream ? slot : 0]) * k * k;
+    for (int idx = threadIdx.x; idx < K * K; idx += blockDim.x) {
+        const int r = idx / K, q = idx - r * K;
+        double v = 0.0;
+        if (kd >= 0 && r < k && q < k) v = kd == 2 ? src[r * k + q] : src[q * k + r];
+        dst[idx] = v;
+    }
+}
+
+#endif

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libarbplf_amd.so")
 
 HOST, DEVICE = 0, 1
 ROOT_NONE, ROOT_CUSTOM, ROOT_UNIFORM, ROOT_EQUILIBRIUM = 1, 2, 3, 4
-INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS = range(5)
+INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS, INFO_LL_KERNEL_NS_SUM, INFO_LL_KERNEL_COUNT = range(7)
 OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA = 0, 1, 2, 3, 4
 COEF_PRIOR, COEF_PRIOR_RATE_EDGE, COEF_PRIOR_RATE = 0, 1, 2
 FIT_EM, FIT_LBFGS = 0, 1
@@ -53,6 +53,9 @@ def load_library():
     lib.plk_set_patterns_dense.argtypes = [vp, cl, vp, ci]
     lib.plk_set_site_weights.argtypes = [vp, vp, ci]
     lib.plk_ll.argtypes = [vp, vp, ci, vp]
+    lib.plk_ll_async.argtypes = [vp, vp, vp]
+    lib.plk_sync.argtypes = [vp]
+    lib.plk_set_stream.argtypes = [vp, vp]
     lib.plk_deriv.argtypes = [vp, vp, vp, vp]
     lib.plk_marginal.argtypes = [vp, vp, vp, vp]
     lib.plk_edge_expect.argtypes = [vp, vp, vp, ci, vp, vp, vp]
@@ -170,6 +173,18 @@ class Engine:
         s = np.zeros(2) if want_sum else None
         self._check(self._lib.plk_ll(self._h, p, where, _ptr(s)))
         return out, (tuple(s) if want_sum else None)
+
+    def ll_async(self, sum_device_ptr=None, site_ll_device_ptr=None):
+        """queue one ll evaluation on the engine's stream; outputs stay in device memory of the caller
+        (raw device pointers: 2 doubles {hi, lo} for the sum, S doubles for the per-site values)"""
+        self._check(self._lib.plk_ll_async(self._h, _ptr(site_ll_device_ptr), _ptr(sum_device_ptr)))
+
+    def sync(self):
+        self._check(self._lib.plk_sync(self._h))
+
+    def set_stream(self, hip_stream):
+        """hip_stream: raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None for the engine's own"""
+        self._check(self._lib.plk_set_stream(self._h, ctypes.c_void_p(int(hip_stream)) if hip_stream else None))
 
     def deriv(self, edge_mask=None, per_site=True, want_sums=True):
         mask = _i32(edge_mask) if edge_mask is not None else None

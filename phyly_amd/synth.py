@@ -364,4 +364,5 @@ class Workload:
         I = self.N - self.T
         A_ll = 2 * (I - 1) * C * self.k * 8 + self.N + 8
         W_ll = C * self.E * (2 * self.k * self.k + self.k) + 2 * C * self.k
-        return dict(A_ll=A_ll, W_ll=W_ll, compulsory=self.N + 8)
+        A_deriv = 6 * (I - 1) * C * self.k * 8 + self.N      # site-aggregated gradient: no per-site output
+        return dict(A_ll=A_ll, W_ll=W_ll, compulsory=self.N + 8, A_deriv=A_deriv)
