@@ -127,8 +127,9 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1;
-    long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_fused_c4 = 1;
+    bool fused_c4 = false;               /* the fused formats are laid out for k_ll_fused4_c4 (four categories per pass) */
+    long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
 static std::string g_create_error;
@@ -228,6 +229,7 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 struct ExpmPost {
     const int *edge_slot;      /* [2][E]: matrix index of the edge or -1 | tip slot of the edge or -1; null: no post */
     int nmat1, ntips1, nchar;  /* matrices / tip slots per category (incl. the spare / pseudo one), definitions */
+    int c4;                    /* matrix stream [group of 4 categories][matrix][category][16] (k_ll_fused4_c4) */
     const double *defs;        /* [nchar][4] */
     double *PS, *tip;
 };
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
             for (int idx = threadIdx.x; idx < 16; idx += blockDim.x) {
                 const int j = idx >> 2, i = idx & 3;
                 const double v = O[i * 4 + j].hi;
-                post.PS[((size_t)c * post.nmat1 + mi) * 16 + idx] = v < 0 ? 0.0 : v;
+                const size_t slot = post.c4 ? ((size_t)(c >> 2) * post.nmat1 + mi) * 4 + (c & 3) : (size_t)c * post.nmat1 + mi;
+                post.PS[slot * 16 + idx] = v < 0 ? 0.0 : v;
             }
         if (t >= 0)
             for (int idx = threadIdx.x; idx < post.nchar * 4; idx += blockDim.x) {
@@ -501,6 +504,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
+#include "plk_fused4_c4.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_vec.h"
@@ -662,6 +666,8 @@ struct UpArgs {
      * node_scale[N] = slot or -1 (null = no rescaling), SC[(slot*C + c)][n] = 2^-e, CW[C][n] = 2^(X_c - Xmax) */
     const int *node_scale;
     double *SC, *CW, *XC;
+    double *XM;          /* [n] or null: the common exponent Xmax of the site (LH and the edge forms are at 2^Xmax) */
+    const double *XMdiv; /* [n] or null: Xmax of the model LHdiv belongs to (second-order passes) */
     const uint8_t *codes;
     const double *defs;  /* [nchar][K] */
     const double *B;     /* [N][k][S] */
@@ -774,9 +780,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
             }
             const int slot = a.node_scale ? as_uniform(a.node_scale)[nd] : -1;
             if (slot >= 0) {
-                double mx = 0.0;
+                double mx = 0.0;       /* |.|: the vectors of an edge-modified model (plk_hess) are not sign definite */
 #pragma unroll
-                for (int i = 0; i < K; i++) mx = fmax(mx, acc[i]);
+                for (int i = 0; i < K; i++) mx = fmax(mx, fabs(acc[i]));
                 double sc = 1.0;
                 if (mx > 0x1p-1000 && mx < 0x1p+1000) {
                     const int e = ilogb(mx);
@@ -805,12 +811,13 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_down_store(UpArgs a)
         }
         if (!a.node_scale) { lh_total = fma(as_uniform(a.cat_prior)[c], lh_c, lh_total); continue; }
         lh_c *= as_uniform(a.cat_prior)[c];
-        if (lh_c > 0.0 && X > xmax) xmax = X;
+        if (lh_c != 0.0 && X > xmax) xmax = X;
         if (valid) { a.XC[(size_t)c * n + sl] = (double)X; a.CW[(size_t)c * n + sl] = lh_c; }
     }
     if (a.node_scale && valid) {
         /* combine the categories at the largest exponent: LH = sum_c prior_c lh_c 2^(X_c - Xmax) */
         if (xmax == INT_MIN) xmax = 0;
+        if (a.XM) a.XM[sl] = (double)xmax;
         for (int c = 0; c < a.C; c++) {
             const double w = ldexp(1.0, (int)a.XC[(size_t)c * n + sl] - xmax);
             lh_total = fma(a.CW[(size_t)c * n + sl], w, lh_total);
@@ -838,7 +845,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_up(UpArgs a)
     const long slc = valid ? sl : a.n - 1;
     const long sg = a.s0 + slc;
     const size_t n = (size_t)a.n;
-    const double inv = 1.0 / (a.LHdiv ? a.LHdiv[slc] : a.LH[slc]);
+    /* second-order passes divide by the likelihood of the unmodified model, which sits at its own exponent */
+    double inv = 1.0 / (a.LHdiv ? a.LHdiv[slc] : a.LH[slc]);
+    if (a.LHdiv && a.XM && a.XMdiv) inv = ldexp(inv, (int)(a.XM[slc] - a.XMdiv[slc]));
     const int root = as_uniform(a.preorder)[0];
 
     /* root: forward vector = root prior weights; its marginal */
@@ -1076,9 +1085,10 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (!plk_live(h)) return PLK_E_ARG;
     if (option == PLK_OPT_FORCE_GENERIC) { h->opt_force_generic = value; h->prog_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
-    if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; return PLK_OK; }
-    if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; return PLK_OK; }
+    if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; h->fmt_dirty = true; return PLK_OK; }
+    if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
+    if (option == PLK_OPT_FUSED_C4) { h->opt_fused_c4 = value; h->fmt_dirty = true; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1116,6 +1126,7 @@ extern "C" int plk_get_info(plk_engine *h, int what, long *out)
     case PLK_INFO_LL_KERNEL_NS_SUM: *out = h->evk_sum_ns; h->evk_sum_ns = 0; return PLK_OK;
     case PLK_INFO_LL_KERNEL_COUNT: *out = h->evk_count; h->evk_count = 0; return PLK_OK;
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
+    case PLK_INFO_LL_VARIANT: *out = h->info_ll_variant; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
     case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
     case PLK_INFO_LAST_LL_KERNEL_NS: *out = h->info_ll_kernel_ns; return PLK_OK;
@@ -1185,7 +1196,7 @@ static int run_expm(plk_engine *h, bool post = false)
     post = post && k == 4 && h->fmt_kind == 1 && !h->fmt_dirty && h->d_edge_slot;
     if (post) {
         ep.edge_slot = h->d_edge_slot; ep.nmat1 = (int)h->mat_edge.size() + 1; ep.ntips1 = (int)h->tip_edge.size() + 1;
-        ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip;
+        ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip; ep.c4 = h->fused_c4 ? 1 : 0;
     }
     hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
@@ -1421,6 +1432,16 @@ static int upload_formats(plk_engine *h, long kind)
         if ((rc = dev_upload(h, &h->d_edge_slot, em.data(), em.size()))) return rc;
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * (h->mat_edge.size() + 1) * 16))) return rc;
         if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4))) return rc;
+        /* four categories per pass when they come in fours, the stack fits four slots and four tip tables fit in LDS */
+        h->fused_c4 = h->opt_fused_c4 && h->opt_fused_asm && h->fu.asm_ok && fused_sites_per_lane(h) == 1 && h->C % 4 == 0 &&
+                      h->slots_needed <= 4 &&
+                      plk_fused_lds_bytes(h->pg, h->nchar, h->nchar <= 16 ? PLK_TILE / 2 : PLK_TILE, 4) <= PLK_LDS_LIMIT;
+        /* K1 fills the stream and the tip slots of the edges; the spare matrices stay zero and the pseudo tip slot
+         * (raw definitions) is written here */
+        HIPCHK(h, hipMemsetAsync(h->d_PS, 0, (size_t)h->C * (h->mat_edge.size() + 1) * 16 * sizeof(double), h->stream));
+        hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, h->C), dim3(64), 0, h->stream,
+                           h->E, ntips + 1, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+        HIPCHK(h, hipGetLastError());
     } else {
         /* OP_MATVEC ops name the next OP_MATVEC (y, wrapping to the first): the vector kernel touches the
          * cache lines of the next matrix while it multiplies with the current one */
@@ -1466,12 +1487,8 @@ static int build_tables(plk_engine *h, long kind)
 {
     const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size(), K = h->K, C = h->C;
     if (kind == 1) {
-        const int nmat = (int)h->mat_edge.size();
-        /* one spare matrix per category: the kernel always keeps the next matrix of the stream loaded */
-        hipLaunchKernelGGL(k_build_stream, dim3(nmat + 1, C), dim3(64), 0, h->stream,
-                           h->k, K, h->E, nmat + 1, h->d_mat_edge, h->d_P, h->d_PS);
-        hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
-                           h->E, ntips + 1, h->nchar, h->d_tip_edge, h->d_Pdd, h->d_defs, h->d_tip);
+        /* the fused formats are written by K1 itself (ExpmPost) */
+        return run_expm(h, true);
     } else {
         if (nops > 0)
             hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
@@ -1547,19 +1564,24 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.root_mode = h->root_mode; a.first_row = h->fu.first_row;
         const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
         const bool use_asm = NS == 1 && h->fu.asm_ok && h->opt_fused_asm;
+        if (!use_asm && h->fused_c4) { h->err = "internal: fused formats are laid out for four categories per pass"; return PLK_E_ARG; }
         const int D = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : 16);
         if (use_asm) {
             FusedAsmArgs aa;
             aa.f = a; aa.words = h->d_words;
             aa.first_tip = h->fu.asm_first_tip; aa.first_row = h->fu.asm_first_row; aa.second_row = h->fu.asm_second_row;
             aa.pack4 = h->nchar <= 16 ? 1 : 0;
-            const size_t lds_asm = plk_fused_lds_bytes(h->pg, h->nchar, aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
+            const int ncat = h->fused_c4 ? 4 : 1;
+            const size_t lds_asm = plk_fused_lds_bytes(h->pg, h->nchar, aa.pack4 ? PLK_TILE / 2 : PLK_TILE, ncat);
             /* replay the interpreter's fetches and LDS addresses on the host before launching (plk_program.h) */
-            const std::string bad = plk_fused_check_asm(h->N, h->pg, h->fu, h->nchar, D, aa.pack4, lds_asm);
+            const std::string bad = plk_fused_check_asm(h->N, h->pg, h->fu, h->nchar, D, aa.pack4, lds_asm, ncat);
             if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
-            if (D == 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            h->info_ll_variant = h->fused_c4 ? 2 : 1;
+            if (h->fused_c4) hipLaunchKernelGGL(k_ll_fused4_c4, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            else if (D == 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
             else hipLaunchKernelGGL(k_ll_fused4_asm<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
         } else {
+            h->info_ll_variant = 3;
             const std::string bad = plk_fused_check_cpp(h->N, h->pg, h->fu, h->nchar, NS == 2 && D == 16 ? 8 : D, NS, lds);
             if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
             if (NS == 2) {
@@ -2240,7 +2262,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.pat_mode = h->pat_mode; a.root_mode = h->root_mode;
         a.dzero = dzero;
-        a.mod_edge = -1; a.DN = nullptr; a.D2T = nullptr; a.LHdiv = nullptr;
+        a.mod_edge = -1; a.DN = nullptr; a.D2T = nullptr; a.LHdiv = nullptr; a.XM = nullptr; a.XMdiv = nullptr;
         a.node_scale = d_ns;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
@@ -2640,7 +2662,9 @@ static void launch_hess_pass_k(plk_engine *h, const UpArgs &a, unsigned grid)
  * dP_j = r Q P_j in the role of P_j and r^2 Q Q P_j in the role of dP_j: the derivative of that model with
  * respect to edge i is the second derivative (i, j) of the original one -- the reference's substitution of Q
  * along both root paths (src/arbplfhess.c:343-437) done for all i at once in O(E k^2) per site and row.
- * E + 1 passes per site chunk; vector kernels (no rescaling: site likelihoods must stay above ~1e-300).
+ * E + 1 passes per site chunk on the generic vector kernels, with the same exact power-of-two rescaling as the
+ * first-order passes (each pass stores its factors; the common exponents of the modified and the unmodified model
+ * are reconciled in the division).
  */
 extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
 {
@@ -2665,11 +2689,11 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
             Q2[(size_t)i * k + j] = acc.hi; Q2[kk + (size_t)i * k + j] = acc.lo;
         }
     double *d_Q2 = nullptr, *d_d2P = nullptr, *d_PT = nullptr, *d_PN = nullptr, *d_DT = nullptr, *d_DN = nullptr, *d_D2T = nullptr;
-    double *d_LH0 = nullptr, *d_D0 = nullptr;
+    double *d_LH0 = nullptr, *d_D0 = nullptr, *d_XM0 = nullptr;
     dd *d_G = nullptr;
-    int *d_has = nullptr;
+    int *d_has = nullptr, *d_ns = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = {d_Q2, d_d2P, d_PT, d_PN, d_DT, d_DN, d_D2T, d_LH0, d_D0, d_G, d_has};
+        void *ps[] = {d_Q2, d_d2P, d_PT, d_PN, d_DT, d_DN, d_D2T, d_LH0, d_D0, d_XM0, d_G, d_has, d_ns};
         for (void *p : ps) if (p) (void)hipFree(p);
     };
     if ((rc = dev_upload(h, &d_Q2, Q2.data(), Q2.size())) || (rc = dev_alloc(h, &d_d2P, (size_t)C * E * kk)) ||
@@ -2686,7 +2710,15 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
     { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
 
-    const size_t per_site = ((size_t)(E + 2 * (size_t)N) * C * k + 2 + 2 * (size_t)E) * sizeof(double);
+    /* exact power-of-two rescaling as in the first-order passes (trees of any size): the traversal program marks the
+     * nodes, the factors are stored per pass, every pass reports the common exponent of its site likelihoods */
+    if (h->prog_dirty) { if ((rc = build_program(h))) { cleanup(); return rc; } }
+    std::vector<int> node_scale(N, -1);
+    int nsc = 0;
+    for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a] && h->scale_node[a]) node_scale[a] = nsc++;
+    if ((rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N))) { cleanup(); return rc; }
+    const size_t per_site_d = (size_t)(E + 2 * (size_t)N) * C * k + (size_t)(nsc + 2) * C + 2 + (size_t)E;
+    const size_t per_site = (per_site_d + 2 + (size_t)E) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -2695,8 +2727,9 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
     if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
     if (chunk < 1) { cleanup(); h->err = "plk_hess: not enough device memory for one site"; return PLK_E_NOMEM; }
     if (chunk < S) chunk = std::max<long>(GEN_BLOCK, chunk / GEN_BLOCK * GEN_BLOCK);
-    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, ((size_t)(E + 2 * (size_t)N) * C * k + 1 + (size_t)E) * (size_t)chunk)) ||
-        (rc = dev_alloc(h, &d_LH0, (size_t)chunk)) || (rc = dev_alloc(h, &d_D0, (size_t)E * chunk))) { cleanup(); return rc; }
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site_d * (size_t)chunk)) ||
+        (rc = dev_alloc(h, &d_LH0, (size_t)chunk)) || (rc = dev_alloc(h, &d_XM0, (size_t)chunk)) ||
+        (rc = dev_alloc(h, &d_D0, (size_t)E * chunk))) { cleanup(); return rc; }
 
     std::vector<long double> Hrow((size_t)E * E, 0.0L), G((size_t)E * E, 0.0L);
     std::vector<dd> gh((size_t)E * E);
@@ -2708,22 +2741,27 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
         a.dzero = 1;
         a.indptr = h->d_indptr; a.indices = h->d_indices; a.preorder = h->d_preorder; a.node_has_data = d_has;
         a.PT = d_PT; a.PN = d_PN; a.DT = d_DT; a.DN = d_DN; a.D2T = d_D2T;
-        a.node_scale = nullptr; a.SC = nullptr; a.CW = nullptr; a.XC = nullptr;
+        a.node_scale = d_ns;
         a.codes = h->d_codes; a.defs = h->d_defs; a.B = h->d_B;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.edge_mask = nullptr; a.node_mask = nullptr;
         double *p = h->d_work;
         a.EV = p; p += (size_t)E * C * k * n;
         a.LN = p; p += (size_t)N * C * k * n;
         a.FN = p; p += (size_t)N * C * k * n;
+        a.SC = p; p += (size_t)nsc * C * n;
+        a.CW = p; p += (size_t)C * n;
+        a.XC = p; p += (size_t)C * n;
+        a.XM = p; p += n;
         a.LH = p; p += n;
         a.DV = p; p += (size_t)E * n;
         a.MV = nullptr;
         const unsigned grid = (unsigned)((n + GEN_BLOCK - 1) / GEN_BLOCK);
         const double *w = h->d_w ? h->d_w + s0 : nullptr;
         /* pass 0: the model itself -> f and g / f */
-        a.mod_edge = -1; a.LHdiv = nullptr;
+        a.mod_edge = -1; a.LHdiv = nullptr; a.XMdiv = nullptr;
         launch_hess_pass_k(h, a, grid);
         hipError_t e = hipMemcpyAsync(d_LH0, a.LH, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_XM0, a.XM, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_D0, a.DV, (size_t)E * n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_gram, dim3(E, E), dim3(256), 0, h->stream, E, n, d_D0, w, d_G);
@@ -2734,7 +2772,7 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
         for (int i = 0; i < E; i++)
             for (int j = 0; j <= i; j++) G[(size_t)i * E + j] += (long double)gh[(size_t)i * E + j].hi + (long double)gh[(size_t)i * E + j].lo;
         /* passes 1..E: row j of the likelihood Hessian, normalised by the unmodified likelihood */
-        a.LHdiv = d_LH0;
+        a.LHdiv = d_LH0; a.XMdiv = d_XM0;
         for (int j = 0; j < E; j++) {
             a.mod_edge = j;
             launch_hess_pass_k(h, a, grid);

@@ -272,10 +272,10 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
     fu.asm_ok = pg.slots_needed <= 8 && ntips + 1 < 8192 && pg.obs_nodes.size() < 65536;
 }
 
-/* dynamic LDS of the fused ll kernels: tip tables of one category (ntips + the pseudo slot) + staged code rows */
-static inline size_t plk_fused_lds_bytes(const PlkProgram &pg, int nchar, int bytes_per_row)
+/* dynamic LDS of the fused ll kernels: tip tables of ncat categories (ntips + the pseudo slot each) + staged code rows */
+static inline size_t plk_fused_lds_bytes(const PlkProgram &pg, int nchar, int bytes_per_row, int ncat = 1)
 {
-    return (size_t)(pg.tip_edge.size() + 1) * nchar * 4 * sizeof(double) + pg.obs_nodes.size() * (size_t)bytes_per_row;
+    return (size_t)ncat * (pg.tip_edge.size() + 1) * nchar * 4 * sizeof(double) + pg.obs_nodes.size() * (size_t)bytes_per_row;
 }
 
 /* the observation sequence of the program: (tip slot incl. pseudo slot, staged row) per observation op */
@@ -298,7 +298,7 @@ static inline void plk_obs_sequence(int N, const PlkProgram &pg, std::vector<int
  * to each observation op are the ones the program asks for.  pack4: two codes per staged byte (nchar <= 16).
  */
 static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const PlkFused &fu, int nchar, int D, int pack4,
-                                              size_t lds_bytes_launched)
+                                              size_t lds_bytes_launched, int ncat_lds = 1)
 {
     const int nops = (int)pg.ops.size(), ntips1 = (int)pg.tip_edge.size() + 1, nobs = (int)pg.obs_nodes.size();
     const int nmat = (int)fu.mat_edge.size();
@@ -309,7 +309,10 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
     if (fu.words.size() % 8 != 0 || (int)fu.words.size() < ((nops + 1 + 7) / 8) * 8 + 8) return "asm program: word buffer too short";
     const size_t row_bytes = pack4 ? PLK_TILE / 2 : PLK_TILE;
     const size_t tip_bytes = (size_t)ntips1 * nchar * 32, code_bytes = (size_t)nobs * row_bytes;
-    if (tip_bytes + code_bytes > lds_bytes_launched) return "asm program: LDS image larger than the launch's dynamic LDS";
+    /* k_ll_fused4_c4 keeps the tip tables of ncat_lds = 4 categories in LDS; the per-category addresses are the
+     * single-table ones plus a multiple of tip_bytes */
+    if (ncat_lds != 1 && ncat_lds != 4) return "asm program: categories per pass";
+    if ((size_t)ncat_lds * tip_bytes + code_bytes > lds_bytes_launched) return "asm program: LDS image larger than the launch's dynamic LDS";
     if (lds_bytes_launched > PLK_LDS_LIMIT) return "asm program: dynamic LDS above the limit";
     if (nobs < 1) return "asm program: no observation rows";
     std::vector<int> slot, rowv, opc;
@@ -516,24 +519,13 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
             uv.rec.insert(uv.rec.end(), cr, cr + 4);
         }
         uv.nvisits++;
-        if (deg == 2) {
-            for (int j = 1; j >= 0; j--) {
-                const int idx = start + j;
-                if (edge_tip[idx] >= 0) continue;
-                put(0, idx);
-                if (flags(idx, ix[idx]) & PLK_UP_WANT_D) put(1, idx);
-            }
-            for (int j = 1; j >= 0; j--)
-                if (flags(start + j, ix[start + j]) & PLK_UP_WANT_F) put(2, start + j);
-        } else {
-            for (int j = 0; j < deg; j++) {
-                const int idx = start + j, fl = flags(idx, ix[idx]);
-                if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
-                for (int j2 = 0; j2 < deg; j2++)
-                    if (j2 != j && edge_tip[start + j2] < 0) put(0, start + j2);
-                if ((fl & PLK_UP_WANT_D) && edge_tip[idx] < 0) put(1, idx);
-                if (fl & PLK_UP_WANT_F) put(2, idx);
-            }
+        for (int j = 0; j < deg; j++) {
+            const int idx = start + j, fl = flags(idx, ix[idx]);
+            if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
+            for (int j2 = 0; j2 < deg; j2++)
+                if (j2 != j && edge_tip[start + j2] < 0) put(0, start + j2);
+            if ((fl & PLK_UP_WANT_D) && edge_tip[idx] < 0) put(1, idx);
+            if (fl & PLK_UP_WANT_F) put(2, idx);
         }
     }
 }
@@ -562,23 +554,13 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
             if (((fl & PLK_UP_STORE_F) != 0) != (t < 0) || (t < 0 && !(fl & PLK_UP_WANT_F))) return plk_fmt("up visits: flags of an internal child in visit %ld", v);
             if (!deriv && (fl & PLK_UP_WANT_D)) return "up visits: derivative flag without a derivative pass";
         }
-        if (deg == 2) {
-            for (int j = 1; j >= 0; j--)
-                if (ch[4 * j + 1] < 0) {
-                    if (!need(0, e0 + j)) return plk_fmt("up visits: stream mismatch (message) in visit %ld", v);
-                    if ((ch[4 * j + 2] & PLK_UP_WANT_D) && !need(1, e0 + j)) return plk_fmt("up visits: stream mismatch (edge form) in visit %ld", v);
-                }
-            for (int j = 1; j >= 0; j--)
-                if ((ch[4 * j + 2] & PLK_UP_WANT_F) && !need(2, e0 + j)) return plk_fmt("up visits: stream mismatch (forward) in visit %ld", v);
-        } else {
-            for (int j = 0; j < deg; j++) {
-                const int fl = ch[4 * j + 2];
-                if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
-                for (int j2 = 0; j2 < deg; j2++)
-                    if (j2 != j && ch[4 * j2 + 1] < 0 && !need(0, e0 + j2)) return plk_fmt("up visits: stream mismatch (sibling) in visit %ld", v);
-                if ((fl & PLK_UP_WANT_D) && ch[4 * j + 1] < 0 && !need(1, e0 + j)) return plk_fmt("up visits: stream mismatch (edge form) in visit %ld", v);
-                if ((fl & PLK_UP_WANT_F) && !need(2, e0 + j)) return plk_fmt("up visits: stream mismatch (forward) in visit %ld", v);
-            }
+        for (int j = 0; j < deg; j++) {
+            const int fl = ch[4 * j + 2];
+            if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
+            for (int j2 = 0; j2 < deg; j2++)
+                if (j2 != j && ch[4 * j2 + 1] < 0 && !need(0, e0 + j2)) return plk_fmt("up visits: stream mismatch (sibling) in visit %ld", v);
+            if ((fl & PLK_UP_WANT_D) && ch[4 * j + 1] < 0 && !need(1, e0 + j)) return plk_fmt("up visits: stream mismatch (edge form) in visit %ld", v);
+            if ((fl & PLK_UP_WANT_F) && !need(2, e0 + j)) return plk_fmt("up visits: stream mismatch (forward) in visit %ld", v);
         }
         for (int j = 0; j < deg; j++) if (ch[4 * j + 2] & PLK_UP_STORE_F) f_written[ch[4 * j + 3]] = 1;
         vp += 8 + 4 * (size_t)deg;

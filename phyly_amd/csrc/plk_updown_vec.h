@@ -16,8 +16,8 @@
  *   - down pass = depth-first traversal of the post-order program: every L_a is written once, at the product that
  *     consumes it; vectors waiting for a sibling subtree go to HBM stack slots (they come back from L2 /
  *     Infinity Cache);
- *   - up pass: the two children of a node are handled in one visit (F_a, L_b0, L_b1 read once; the products
- *     P_e L_b and M_e L_b share their input), leaf edges gather P_e B_b and M_e B_b from double-double built tables;
+ *   - up pass: one edge at a time with ~130 live registers (3-4 waves per SIMD); leaf edges gather P_e B_b and
+ *     M_e B_b from double-double built tables;
  *   - the matrices of the up pass are laid out as a stream in the exact order of use (built per query), so the
  *     64-byte lines of the next product's matrix are requested through the scalar cache while the current product
  *     runs (vec_touch of plk_vec.h: waited for inside the asm statement);
@@ -76,40 +76,20 @@ __device__ __forceinline__ void udv_gather(const double *row, double (&out)[K])
 #pragma unroll
     for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; out[i] = v.x; out[i + 1] = v.y; }
 }
+/* all k entries equal?  (the reference's exact constant-column test, src/arb_mat_extras.c:36-51.)  Compared bit
+ * for bit with integer operations: K - 1 floating-point compares would each produce a lane mask in an SGPR pair, and
+ * the compiler kept them all live (845 spilled SGPRs in k_down_vec<20>).  +0.0 and -0.0 count as different here; the
+ * general product then runs, which is still correct. */
 template <int K>
 __device__ __forceinline__ bool udv_const(const double (&x)[K], int k)
 {
-    bool c = true;
+    const unsigned lo0 = (unsigned)__double2loint(x[0]), hi0 = (unsigned)__double2hiint(x[0]);
+    unsigned diff = 0;
 #pragma unroll
-    for (int i = 1; i < K; i++) c = c && (i >= k || x[i] == x[0]);
-    return c;
+    for (int i = 1; i < K; i++)
+        if (i < k) diff |= ((unsigned)__double2loint(x[i]) ^ lo0) | ((unsigned)__double2hiint(x[i]) ^ hi0);
+    return diff == 0;
 }
-/* acc = M x, M[j*K + i] multiplies x[j] into acc[i] (uniform pointer: SGPR operands) */
-template <int K>
-__device__ __forceinline__ void udv_matvec(const PLK_AS4 double *M, const double (&x)[K], double (&acc)[K])
-{
-#pragma unroll
-    for (int i = 0; i < K; i++) acc[i] = M[i] * x[0];
-#pragma unroll
-    for (int j = 1; j < K; j++) {
-#pragma unroll
-        for (int i = 0; i < K; i++) acc[i] = fma(M[j * K + i], x[j], acc[i]);
-    }
-}
-/* two products that share their input */
-template <int K>
-__device__ __forceinline__ void udv_matvec2(const PLK_AS4 double *M1, const PLK_AS4 double *M2, const double (&x)[K],
-                                            double (&a1)[K], double (&a2)[K])
-{
-#pragma unroll
-    for (int i = 0; i < K; i++) { a1[i] = M1[i] * x[0]; a2[i] = M2[i] * x[0]; }
-#pragma unroll
-    for (int j = 1; j < K; j++) {
-#pragma unroll
-        for (int i = 0; i < K; i++) { a1[i] = fma(M1[j * K + i], x[j], a1[i]); a2[i] = fma(M2[j * K + i], x[j], a2[i]); }
-    }
-}
-
 /* ---------------------------------------------------------------------------------------------------------- */
 template <int K>
 __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *__restrict__ obs_nodes)
@@ -142,7 +122,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
                 const bool cst = udv_const<K>(cur, a.k);
                 const double x0 = cur[0];
                 double acc[K];
-                udv_matvec<K>(PTc + (size_t)oy * K * K, cur, acc);
+                vec_matvec<K>(PTc + (size_t)oy * K * K, cur, acc);
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = cst ? (i < a.k ? x0 : 0.0) : acc[i];   /* src/util.c:276-283 */
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
@@ -207,15 +187,12 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
  *   per child (4 ints): child node b, tip slot or -1, UDV_* flags, storage index of b (internal) or -1;
  *   children with a CSR edge index idx = first_edge + position: the header's int [5] holds first_edge.
  * Matrix stream MS (per category): the matrices in the order the visit code below consumes them:
- *   two children:  for j = 1, 0: internal child j: P_ej^T-layout (PT) [+ M_ej (DT) if WANT_D];  then for j = 1, 0:
- *                  if WANT_F: plain P_ej (PN)
- *   otherwise:     per child in order: for every internal sibling PT(sibling); internal child with WANT_D: DT;
- *                  WANT_F: PN
+ *   per child in order: for every internal sibling PT(sibling); internal child with WANT_D: DT(child); WANT_F: PN(child)
  * (the host builder plk_up_visits_build() and this kernel are the two halves of that contract; the stream always has one
  * spare matrix at the end for the look-ahead)
  */
 template <int K, bool DERIV, bool MARG>
-__global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
+__global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_up_vec(UpVecArgs a)
 {
     const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
     const bool valid = sl < a.n;
@@ -266,20 +243,6 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
             const int nd = vis[vp], deg = vis[vp + 1], nd_int = vis[vp + 2], slot = vis[vp + 3], hd = vis[vp + 4], e0 = vis[vp + 5];
             const PLK_AS4 int *ch = vis + vp + 8;
             vp += 8 + 4 * deg;
-            /* forward vector of the node, with its own observation and its rescaling factor folded in */
-            double F[K];
-            udv_load<K>(a.FN + ((size_t)nd_int * a.C + c) * K * n, n, slc, F);
-            if (hd) {
-                double bv[K];
-                udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * K, bv);
-#pragma unroll
-                for (int i = 0; i < K; i++) F[i] *= bv[i];
-            }
-            if (slot >= 0) {
-                const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
-#pragma unroll
-                for (int i = 0; i < K; i++) F[i] *= sc;
-            }
             /* accumulate over categories in the output planes: first category writes, later ones add */
 #define UDV_OUT_D(EDGE, VAL)                                                                              \
             do { if (valid) { double *dp_ = a.DV + (size_t)(EDGE) * n + sl;                               \
@@ -289,123 +252,29 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
                  double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
                  const double t_ = pc * FB[i] * LB[i]; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
 
-            if (deg == 2) {
-                const int b0 = ch[0], t0 = ch[1], f0 = ch[2], i0 = ch[3];
-                const int b1 = ch[4], t1 = ch[5], f1 = ch[6], i1 = ch[7];
-                double m0[K], y0[K], m1[K], y1[K];
-                /* child 1, then child 0: message m = P L (or table), edge-form vector y = M L (or table) */
-                if (t1 >= 0) {
-                    const int cd = a.codes[(size_t)b1 * a.Spad + sg];
-                    udv_gather<K>(tipc + ((size_t)t1 * a.nchar + cd) * K, m1);
-                    if (DERIV && (f1 & UDV_WANT_D)) udv_gather<K>(dtipc + ((size_t)t1 * a.nchar + cd) * K, y1);
-                } else {
-                    double L[K];
-                    udv_load<K>(a.LN + ((size_t)i1 * a.C + c) * K * n, n, slc, L);
-                    const bool cst = udv_const<K>(L, a.k);
-                    if (DERIV && (f1 & UDV_WANT_D)) {
-                        vec_touch<K>(ms + 2 * KK); vec_touch<K>(ms + 3 * KK);
-                        udv_matvec2<K>(ms, ms + KK, L, m1, y1);
-                        ms += 2 * KK;
-                        if (a.dzero && cst) {
-#pragma unroll
-                            for (int i = 0; i < K; i++) y1[i] = 0.0;
-                        }
-                    } else {
-                        vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, L, m1);
-                        ms += KK;
-                    }
-                    if (cst) {
-#pragma unroll
-                        for (int i = 0; i < K; i++) m1[i] = i < a.k ? L[0] : 0.0;
-                    }
-                }
-                if (t0 >= 0) {
-                    const int cd = a.codes[(size_t)b0 * a.Spad + sg];
-                    udv_gather<K>(tipc + ((size_t)t0 * a.nchar + cd) * K, m0);
-                    if (DERIV && (f0 & UDV_WANT_D)) udv_gather<K>(dtipc + ((size_t)t0 * a.nchar + cd) * K, y0);
-                } else {
-                    double L[K];
-                    udv_load<K>(a.LN + ((size_t)i0 * a.C + c) * K * n, n, slc, L);
-                    const bool cst = udv_const<K>(L, a.k);
-                    if (DERIV && (f0 & UDV_WANT_D)) {
-                        vec_touch<K>(ms + 2 * KK); vec_touch<K>(ms + 3 * KK);
-                        udv_matvec2<K>(ms, ms + KK, L, m0, y0);
-                        ms += 2 * KK;
-                        if (a.dzero && cst) {
-#pragma unroll
-                            for (int i = 0; i < K; i++) y0[i] = 0.0;
-                        }
-                    } else {
-                        vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, L, m0);
-                        ms += KK;
-                    }
-                    if (cst) {
-#pragma unroll
-                        for (int i = 0; i < K; i++) m0[i] = i < a.k ? L[0] : 0.0;
-                    }
-                }
-                /* child 1: fe1 = F o m0 */
-                {
-                    double fe[K];
-#pragma unroll
-                    for (int i = 0; i < K; i++) fe[i] = F[i] * m0[i];
-                    if (DERIV && (f1 & UDV_WANT_D)) {
-                        double d = 0.0;
-#pragma unroll
-                        for (int i = 0; i < K; i++) d = fma(fe[i], y1[i], d);
-                        UDV_OUT_D(e0 + 1, pc * d);
-                    }
-                    if (f1 & UDV_WANT_F) {
-                        double fb[K];
-                        vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, fe, fb);
-                        ms += KK;
-                        if ((f1 & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)i1 * a.C + c) * K * n, n, slc, fb);
-                        if (MARG && (f1 & UDV_WANT_M)) {
-                            double lb[K];
-                            if (t1 >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b1 * a.Spad + sg]) * K, lb);
-                            else udv_load<K>(a.LN + ((size_t)i1 * a.C + c) * K * n, n, slc, lb);
-                            UDV_OUT_M(b1, fb, lb);
-                        }
-                    }
-                }
-                /* child 0: fe0 = F o m1 */
-                {
-                    double fe[K];
-#pragma unroll
-                    for (int i = 0; i < K; i++) fe[i] = F[i] * m1[i];
-                    if (DERIV && (f0 & UDV_WANT_D)) {
-                        double d = 0.0;
-#pragma unroll
-                        for (int i = 0; i < K; i++) d = fma(fe[i], y0[i], d);
-                        UDV_OUT_D(e0, pc * d);
-                    }
-                    if (f0 & UDV_WANT_F) {
-                        double fb[K];
-                        vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, fe, fb);
-                        ms += KK;
-                        if ((f0 & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)i0 * a.C + c) * K * n, n, slc, fb);
-                        if (MARG && (f0 & UDV_WANT_M)) {
-                            double lb[K];
-                            if (t0 >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b0 * a.Spad + sg]) * K, lb);
-                            else udv_load<K>(a.LN + ((size_t)i0 * a.C + c) * K * n, n, slc, lb);
-                            UDV_OUT_M(b0, fb, lb);
-                        }
-                    }
-                }
-                continue;
-            }
-            /* one child, or three and more (e.g. the root of an unrooted tree): one edge at a time, sibling messages
-             * recomputed for every edge */
+            /* one edge at a time; the messages of the siblings are recomputed for every edge (a binary node costs three
+             * products per internal edge either way; handling both children in one visit would keep F_a, both child
+             * messages and both edge-form vectors live -- 300 registers at K = 20, one wave per SIMD, measured 9 M
+             * sites/s at BASELINE config 4 -- whereas this form needs ~130 and the second reading of F_a / L_b within
+             * a visit comes from L2 / Infinity Cache) */
             for (int j = 0; j < deg; j++) {
                 const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
                 if (!(fl & (UDV_WANT_D | UDV_WANT_F))) continue;
+                /* forward vector of the node, with its own observation and its rescaling factor folded in (read again
+                 * for every child -- from L2 the second time -- rather than kept live across the products) */
                 double fe[K];
+                udv_load<K>(a.FN + ((size_t)nd_int * a.C + c) * K * n, n, slc, fe);
+                if (hd) {
+                    double bv[K];
+                    udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * K, bv);
 #pragma unroll
-                for (int i = 0; i < K; i++) fe[i] = F[i];
+                    for (int i = 0; i < K; i++) fe[i] *= bv[i];
+                }
+                if (slot >= 0) {
+                    const double sc = a.SC[((size_t)slot * a.C + c) * n + slc];
+#pragma unroll
+                    for (int i = 0; i < K; i++) fe[i] *= sc;
+                }
                 for (int j2 = 0; j2 < deg; j2++) {
                     if (j2 == j) continue;
                     const int b2 = ch[4 * j2], t2 = ch[4 * j2 + 1], bi2 = ch[4 * j2 + 3];
@@ -415,7 +284,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
                         double L[K];
                         udv_load<K>(a.LN + ((size_t)bi2 * a.C + c) * K * n, n, slc, L);
                         vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, L, m);
+                        vec_matvec<K>(ms, L, m);
                         ms += KK;
                         if (udv_const<K>(L, a.k)) {
 #pragma unroll
@@ -432,7 +301,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
                         double L[K];
                         udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, L);
                         vec_touch<K>(ms + 2 * KK);
-                        udv_matvec<K>(ms, L, y);
+                        vec_matvec<K>(ms, L, y);
                         ms += KK;
                         if (a.dzero && udv_const<K>(L, a.k)) {
 #pragma unroll
@@ -447,7 +316,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_up_vec(UpVecArgs a)
                 if (fl & UDV_WANT_F) {
                     double fb[K];
                     vec_touch<K>(ms + 2 * KK);
-                    udv_matvec<K>(ms, fe, fb);
+                    vec_matvec<K>(ms, fe, fb);
                     ms += KK;
                     if ((fl & UDV_STORE_F) && valid) udv_store<K>(a.FN + ((size_t)bi * a.C + c) * K * n, n, slc, fb);
                     if (MARG && (fl & UDV_WANT_M)) {

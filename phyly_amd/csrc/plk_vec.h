@@ -63,6 +63,8 @@ __device__ __forceinline__ void vec_touch(const PLK_AS4 double *p)
     (void)d;
 }
 
+#include "plk_vec_matvec_asm.h"   /* vec_matvec<K>: the product itself, explicit SGPR banks for K = 16, 20 */
+
 template <int K>
 __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
 {
@@ -94,13 +96,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
                 const int nc = oy <= pc ? c + 1 : c;
                 vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oy) * K * K);
                 double acc[K];
-#pragma unroll
-                for (int i = 0; i < K; i++) acc[i] = M[i] * cur[0];
-#pragma unroll
-                for (int j = 1; j < K; j++) {
-#pragma unroll
-                    for (int i = 0; i < K; i++) acc[i] = fma(M[j * K + i], cur[j], acc[i]);
-                }
+                vec_matvec<K>(M, cur, acc);
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = acc[i];
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {

@@ -123,3 +123,62 @@ def test_random_inputs_match_oracle(oracle):
         _check(json.loads(arbplf.arbplf_hess(s)), want, rel=1e-10)
         done += 1
     assert done >= 20
+
+
+def test_rescaled_passes_tiny_likelihoods(eng, oracle):
+    """site likelihoods far below the double range (each of 64 leaf observations scaled by 1e-15: likelihood ~ 1e-990):
+    the second-order passes rescale like the first-order ones; the Hessian of the LOG likelihood does not depend on
+    the scaling, the binary128 oracle is the checker"""
+    from phyly_amd import synth
+    for T, k, model, S in ((64, 4, "gtr_g4", 5), (48, 5, None, 4)):
+        if model is None:
+            w = synth.Workload(T=T, k=4, tree="yule", model="hky85", seed=33)
+            rng = np.random.default_rng(5)
+            w.k = k
+            w.Q = (rng.random((k, k)) + 0.1).tolist()
+            w.mixture = None
+            w.k0 = None
+            w._cum = None
+            w.defs = np.vstack([np.eye(k), np.ones((1, k))])
+            w.nchar = k + 1
+        else:
+            w = synth.Workload(T=T, k=k, tree="yule", model=model, seed=33)
+        w.setup_engine(eng)
+        codes = w.simulate(S)
+        defs = w.defs.copy()
+        defs[:w.k] *= 1e-15                      # observed states; the all-ones "missing" row stays
+        m, ow = oracle_model(oracle, w, codes)
+        eng.set_patterns_codes(codes, defs)
+        ll, _ = eng.ll()
+        assert np.all(ll < -1500) and np.all(np.isfinite(ll))
+        want = oracle.site_hess(m, ow, defs[codes.T], precise=2).astype(np.longdouble).sum(axis=0).astype(float)
+        got = eng.hess()
+        assert np.all(np.isfinite(got))
+        assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(want))
+
+
+def test_hessian_of_a_600_taxon_tree(eng):
+    """600 taxa, k = 4: site likelihoods ~ e^-830 underflow the double range, E = 1198 second-order passes; rows of the
+    Hessian against central differences of the engine's own (rescaled) gradient"""
+    from phyly_amd import synth
+    w = synth.Workload(T=600, k=4, tree="yule", model="gtr_g4", seed=17)
+    w.setup_engine(eng)
+    codes = w.random_codes(48, seed=4, missing_frac=0.02)     # unrelated leaf states: ll ~ 600 log(1/4)
+    eng.set_patterns_codes(codes, w.defs)
+    ll, _ = eng.ll()
+    assert np.max(ll) < -745                    # every site likelihood is below the smallest double
+    H = eng.hess()
+    assert np.all(np.isfinite(H)) and np.allclose(H, H.T, rtol=0, atol=0)
+    r0 = w.edge_rates_csr.copy()
+    for j in (0, 611, w.E - 1):
+        h = 1e-5 * r0[j]
+        g = []
+        for sgn in (1, -1):
+            r = r0.copy()
+            r[j] += sgn * h
+            eng.update_edge_rates(r)
+            _, s = eng.deriv(per_site=False)
+            g.append(s[:, 0] + s[:, 1])
+        fd = (g[0] - g[1]) / (2 * h)
+        assert np.max(np.abs(fd - H[j])) <= 1e-6 * np.max(np.abs(H[j]))
+    eng.update_edge_rates(r0)
