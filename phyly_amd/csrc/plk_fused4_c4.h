@@ -1,14 +1,14 @@
 /*
- * plk_fused4_c4.h -- k_ll_fused4_c4: the k = 4 fused ll traversal with FOUR rate categories of a site carried through
- * one pass of the traversal program (interpreter in CDNA4 assembly: plk_fused4_c4_asm.h, generated by
- * tools/gen_fused4_c4.py, which also documents the register map).  Included by plk_engine.hip after
- * plk_fused4_asm.h.  Used when the number of categories is a multiple of four (GTR+G4: BASELINE config 3) and the
- * tree needs at most four stack slots; everything else runs k_ll_fused4_asm, one category per pass.
+ * plk_fused4_c4.h -- k_ll_fused4_cn<NC, D>: the k = 4 fused ll traversal with NC = 2 or 4 rate categories of a site
+ * carried through one pass of the traversal program (interpreter in CDNA4 assembly: plk_fused4_c4_asm.h, generated
+ * by tools/gen_fused4_c4.py, which also documents the register map).  Included by plk_engine.hip after
+ * plk_fused4_asm.h.  Used when the number of categories is a multiple of NC (GTR+G4: BASELINE config 3) and the
+ * stack fits (NC = 4: four slots; NC = 2: eight); everything else runs k_ll_fused4_asm, one category per pass.
  *
  * Replaces the same reference code as k_ll_fused4_asm: src/arbplfll.c:139-170 (site and category loops) x
  * src/evaluate_site_lhood.c:21-57 x src/util.c:242-301 x src/model.c:283-350.
  *
- * LDS: the tip tables of the four categories of the group (4 x ntips x nchar x 32 bytes), then the staged code rows of
+ * LDS: the tip tables of the NC categories of the group (NC x ntips x nchar x 32 bytes), then the staged code rows of
  * the tile.  Matrix stream: [group][matrix][category in group][16] (K1 writes it in this order).
  */
 #ifndef PLK_FUSED4_C4_H
@@ -16,13 +16,14 @@
 
 #include "plk_fused4_c4_asm.h"
 
-__global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_c4(FusedAsmArgs aa)
+template <int NC, int D>
+__global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_cn(FusedAsmArgs aa)
 {
     const FusedArgs &a = aa.f;
     extern __shared__ double lds_dyn[];
     double *tip_lds = lds_dyn;
     const int tip_doubles = a.ntips * a.nchar * 4;                 /* one category */
-    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_dyn + 4 * (size_t)tip_doubles);
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_dyn + NC * (size_t)tip_doubles);
     const long tile0 = (long)blockIdx.x * PLK_TILE;
     const int tid = threadIdx.x;
     const long s = tile0 + tid;
@@ -79,22 +80,22 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_c4(FusedAsmArgs aa)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
-    for (int g = 0; g < a.C; g += 4) {
+    for (int g = 0; g < a.C; g += NC) {
         __syncthreads();
         {
             const double2 *src = reinterpret_cast<const double2 *>(a.tip + (size_t)g * tip_doubles);
             double2 *dst = reinterpret_cast<double2 *>(tip_lds);
-            for (int idx = tid; idx < 2 * tip_doubles; idx += PLK_TILE) dst[idx] = src[idx];      /* 4 categories */
+            for (int idx = tid; idx < NC * tip_doubles / 2; idx += PLK_TILE) dst[idx] = src[idx];      /* NC categories */
         }
         __syncthreads();
-        const double *ms = a.PS + (size_t)g * (a.nmat + 1) * 16;      /* group g / 4: (nmat + 1) x 4 matrices */
+        const double *ms = a.PS + (size_t)g * (a.nmat + 1) * 16;      /* group g / NC: (nmat + 1) x NC matrices */
         p.pv = lane == 2 ? (unsigned)(size_t)ms : (lane == 3 ? (unsigned)((size_t)ms >> 32) : pv_fixed);
         p.ch = code_lds[(p.clane - code_base) + aa.first_row * row_bytes];
-        double lh[4];
-        int esc[4];
-        fused_run_program_c4(lh, esc, p);
+        double lh[NC];
+        int esc[NC];
+        fused_run_program_cn<NC, D>(lh, esc, p);
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
+        for (int cc = 0; cc < NC; cc++) {
             const double term = prior[g + cc] * lh[cc];
             if (term != 0.0) {
                 if (!have) { sum = term; Eexp = esc[cc]; have = true; }

@@ -311,7 +311,7 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
     const size_t tip_bytes = (size_t)ntips1 * nchar * 32, code_bytes = (size_t)nobs * row_bytes;
     /* k_ll_fused4_c4 keeps the tip tables of ncat_lds = 4 categories in LDS; the per-category addresses are the
      * single-table ones plus a multiple of tip_bytes */
-    if (ncat_lds != 1 && ncat_lds != 4) return "asm program: categories per pass";
+    if (ncat_lds != 1 && ncat_lds != 2 && ncat_lds != 4) return "asm program: categories per pass";
     if ((size_t)ncat_lds * tip_bytes + code_bytes > lds_bytes_launched) return "asm program: LDS image larger than the launch's dynamic LDS";
     if (lds_bytes_launched > PLK_LDS_LIMIT) return "asm program: dynamic LDS above the limit";
     if (nobs < 1) return "asm program: no observation rows";

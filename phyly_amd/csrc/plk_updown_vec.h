@@ -57,17 +57,25 @@ struct UpVecArgs {
 #define UDV_WANT_M PLK_UP_WANT_M
 #define UDV_STORE_F PLK_UP_STORE_F /* internal child: F_b is stored */
 
+/* plane i of a stored vector starts at base + i * n (wave-uniform: scalar address arithmetic); the lane adds its
+ * site index as a 32-bit offset, so one VGPR addresses all K planes (n < 2^29 sites per chunk) */
 template <int K>
 __device__ __forceinline__ void udv_load(const double *base, size_t n, long slc, double (&out)[K])
 {
+    const unsigned off = (unsigned)slc;
+    /* pin the (wave-uniform) base in an SGPR pair here: otherwise the compiler hoists K 64-bit lane addresses per
+     * vector out of the loops and keeps them in VGPRs (40 registers for one K = 20 vector) */
+    asm volatile("" : "+s"(base));
 #pragma unroll
-    for (int i = 0; i < K; i++) out[i] = base[(size_t)i * n + slc];
+    for (int i = 0; i < K; i++) out[i] = (base + (size_t)i * n)[off];
 }
 template <int K>
 __device__ __forceinline__ void udv_store(double *base, size_t n, long slc, const double (&v)[K])
 {
+    const unsigned off = (unsigned)slc;
+    asm volatile("" : "+s"(base));
 #pragma unroll
-    for (int i = 0; i < K; i++) base[(size_t)i * n + slc] = v[i];
+    for (int i = 0; i < K; i++) (base + (size_t)i * n)[off] = v[i];
 }
 template <int K>
 __device__ __forceinline__ void udv_gather(const double *row, double (&out)[K])
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
  * spare matrix at the end for the look-ahead)
  */
 template <int K, bool DERIV, bool MARG>
-__global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_up_vec(UpVecArgs a)
+__global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up_vec(UpVecArgs a)
 {
     const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
     const bool valid = sl < a.n;

@@ -30,10 +30,23 @@ Program words: the format of plk_fused4_asm.h (plk_program.h builds and checks i
 """
 
 L = []
-B0 = 20                 # first fixed VGPR: v[B0 : B0 + 91] are the interpreter's, v0 .. v19 are left to the compiler's
-                        # operands (5 inputs, 12 outputs) so that the kernel needs 112 VGPRs + 128 AGPRs: two waves per SIMD
-XB, TB_, TVB, MISC, UB = B0, B0 + 32, B0 + 40, B0 + 72, B0 + 84
-V_TMP, V_CODE, V_EXP, V_T1, V_T2, V_CLANE, V_NSH, V_ADDR = MISC, MISC + 1, MISC + 2, MISC + 6, MISC + 7, MISC + 8, MISC + 9, MISC + 10
+NC = 4                  # categories per pass (set per generated variant)
+B0 = 20                 # first fixed VGPR: v0 .. v19 are left to the compiler's operands (5 inputs, 3 NC outputs)
+XB = TB_ = TVB = MISC = UB = V_TMP = V_CODE = V_EXP = V_T1 = V_T2 = V_CLANE = V_NSH = V_ADDR = NV = 0
+
+
+def set_nc(nc):
+    """register map for nc categories per pass: x (8 nc), T (8), tip values (8 nc), misc (12), U (8)"""
+    global NC, XB, TB_, TVB, MISC, UB, V_TMP, V_CODE, V_EXP, V_T1, V_T2, V_CLANE, V_NSH, V_ADDR, NV
+    NC = nc
+    XB = B0
+    TB_ = XB + 8 * nc
+    TVB = TB_ + 8
+    MISC = TVB + 8 * nc
+    UB = MISC + 12
+    NV = UB + 8 - B0
+    V_TMP, V_CODE, V_EXP = MISC, MISC + 1, MISC + 2
+    V_T1, V_T2, V_CLANE, V_NSH, V_ADDR = MISC + 6, MISC + 7, MISC + 8, MISC + 9, MISC + 10
 
 
 def e(s):
@@ -96,11 +109,11 @@ def tip_prefetch(first):
         e("s_mul_i32 s99, s99, s94")
         e("v_bfe_u32 v%d, v%d, v%d, s100" % (V_T1, V_CODE, V_NSH))
         e("v_lshl_add_u32 v%d, v%d, 5, s98" % (V_ADDR, V_T1))
-    for c in range(4):
+    for c in range(NC):
         r = TVB + 8 * c
         e("ds_read_b128 v[%d:%d], v%d" % (r, r + 3, V_ADDR))
         e("ds_read_b128 v[%d:%d], v%d offset:16" % (r + 4, r + 7, V_ADDR))
-        if c < 3:
+        if c < NC - 1:
             e("v_add_u32 v%d, s101, v%d" % (V_ADDR, V_ADDR))
     if first:
         e("ds_read_u8 v%d, %%[secaddr]" % V_CODE)
@@ -113,12 +126,12 @@ def gen(D):
     global L
     L = []
     # ---- prologue
-    for c in range(4):
+    for c in range(NC):
         for i in range(4):
             r = XB + 8 * c + 2 * i
             e("v_mov_b32 v%d, 0" % r)
             e("v_mov_b32 v%d, 0x3ff00000" % (r + 1))
-    for c in range(4):
+    for c in range(NC):
         e("v_mov_b32 v%d, 0" % (V_EXP + c))
     e("v_mov_b32 v%d, %%[clane]" % V_CLANE)
     e("v_mov_b32 v%d, %%[nshift]" % V_NSH)
@@ -162,17 +175,25 @@ def gen(D):
     # ---- MATVEC: banks A, B hold categories 0, 1 of this matrix on entry and of the next matrix on exit
     e(".Lmatvec_%=:")
     e("s_waitcnt lgkmcnt(0)")
-    matvec(0, 0)
-    load_bank(0, 0x100)
-    matvec(1, 1)
-    e("s_waitcnt lgkmcnt(0)")
-    load_bank(1, 0x180)
-    matvec(2, 0)
-    e("s_waitcnt lgkmcnt(0)")
-    load_bank(0, 0x200)
-    matvec(3, 1)
-    load_bank(1, 0x280)
-    e("s_add_u32 s86, s86, 0x200")
+    if NC == 4:
+        matvec(0, 0)
+        load_bank(0, 0x100)
+        matvec(1, 1)
+        e("s_waitcnt lgkmcnt(0)")
+        load_bank(1, 0x180)
+        matvec(2, 0)
+        e("s_waitcnt lgkmcnt(0)")
+        load_bank(0, 0x200)
+        matvec(3, 1)
+        load_bank(1, 0x280)
+        e("s_add_u32 s86, s86, 0x200")
+    else:
+        # two categories: both banks are refilled for the NEXT matrix, a whole op ahead of their use
+        matvec(0, 0)
+        load_bank(0, 0x100)
+        matvec(1, 1)
+        load_bank(1, 0x180)
+        e("s_add_u32 s86, s86, 0x100")
     e("s_addc_u32 s87, s87, 0")
     e("s_setpc_b64 s[88:89]")
     # ---- TIP_SET / TIP_MUL
@@ -181,12 +202,12 @@ def gen(D):
     e("s_cmp_eq_u32 s97, 0")
     e("s_cbranch_scc1 .Ltipset_%=")
     e(".Ltipmul_nw_%=:")
-    for c in range(4):
+    for c in range(NC):
         for i in range(4):
             e("v_mul_f64 %s, %s, %s" % (X(c, i), X(c, i), TV(c, i)))
     e("s_branch .Ltipnext_%=")
     e(".Ltipset_%=:")
-    for c in range(4):
+    for c in range(NC):
         for i in range(4):
             e("v_mov_b64 %s, %s" % (X(c, i), TV(c, i)))
     e(".Ltipnext_%=:")
@@ -201,17 +222,17 @@ def gen(D):
     e("s_branch .Lpop%d_%%=" % (D - 1))
     for d in range(D):
         e(".Lpop%d_%%=:" % d)
-        for c in range(4):
+        for c in range(NC):
             tb = TB_ if c % 2 == 0 else UB
             for r in range(8):
-                e("v_accvgpr_read_b32 v%d, a%d" % (tb + r, (d * 4 + c) * 8 + r))
+                e("v_accvgpr_read_b32 v%d, a%d" % (tb + r, (d * NC + c) * 8 + r))
             if c >= 1:      # multiply the previous category while this one's reads complete
                 pb = TB_ if (c - 1) % 2 == 0 else UB
                 for i in range(4):
                     e("v_mul_f64 %s, %s, %s" % (X(c - 1, i), X(c - 1, i), T(i, pb)))
         e("s_nop 1")
         for i in range(4):
-            e("v_mul_f64 %s, %s, %s" % (X(3, i), X(3, i), T(i, UB)))
+            e("v_mul_f64 %s, %s, %s" % (X(NC - 1, i), X(NC - 1, i), T(i, UB)))     # NC even: the last category used U
         e("s_setpc_b64 s[88:89]")
     e(".Lpush_%=:")
     e("s_bfe_u32 s97, s96, 0xd0003")
@@ -221,13 +242,13 @@ def gen(D):
     e("s_branch .Lpush%d_%%=" % (D - 1))
     for d in range(D):
         e(".Lpush%d_%%=:" % d)
-        for c in range(4):
+        for c in range(NC):
             for r in range(8):
-                e("v_accvgpr_write_b32 a%d, v%d" % ((d * 4 + c) * 8 + r, XB + 8 * c + r))
+                e("v_accvgpr_write_b32 a%d, v%d" % ((d * NC + c) * 8 + r, XB + 8 * c + r))
         e("s_setpc_b64 s[88:89]")
     # ---- SCALE
     e(".Lscale_%=:")
-    for c in range(4):
+    for c in range(NC):
         e("v_max_u32 v%d, %s, %s" % (V_T1, Xhi(c, 0), Xhi(c, 1)))
         e("v_max3_u32 v%d, %s, %s, v%d" % (V_T1, Xhi(c, 2), Xhi(c, 3), V_T1))
         e("v_lshrrev_b32 v%d, 20, v%d" % (V_T1, V_T1))
@@ -243,18 +264,18 @@ def gen(D):
     # lanes 10..17 of the parameter register (ones for "no prior", 1/4 for uniform)
     for k in range(8):
         e("v_readlane_b32 s%d, %%[pv], %d" % (36 + k, 10 + k))
-    for c in range(4):
+    for c in range(NC):
         e("v_mul_f64 %%[lh%d], s[36:37], %s" % (c, X(c, 0)))
         for i in (1, 2, 3):
             e("v_fma_f64 %%[lh%d], s[%d:%d], %s, %%[lh%d]" % (c, 36 + 2 * i, 37 + 2 * i, X(c, i), c))
         e("v_mov_b32 %%[e%d], v%d" % (c, V_EXP + c))
     e("s_nop 1")
     text = "\n".join('        "%s\\n%s"' % (l, "" if l.endswith(":") else "\\t") for l in L[:-1]) + '\n        "%s"' % L[-1]
-    outs = ", ".join('[lh%d] "=&v"(lh[%d])' % (c, c) for c in range(4))
-    outs += ", " + ", ".join('[e%d] "=&v"(esc[%d])' % (c, c) for c in range(4))
+    outs = ", ".join('[lh%d] "=&v"(lh[%d])' % (c, c) for c in range(NC))
+    outs += ", " + ", ".join('[e%d] "=&v"(esc[%d])' % (c, c) for c in range(NC))
     ins = ", ".join('[%s] "v"(p.%s)' % (n, n) for n in ("ch", "clane", "nshift", "secaddr", "pv"))
-    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % r for r in range(B0, B0 + 92)] + ['"s%d"' % r for r in range(4, 102)] + \
-           ['"a%d"' % r for r in range(32 * D)]
+    clob = ['"memory"', '"scc"', '"vcc"'] + ['"v%d"' % r for r in range(B0, B0 + NV)] + ['"s%d"' % r for r in range(4, 102)] + \
+           ['"a%d"' % r for r in range(8 * NC * D)]
     rows = []
     line = "          "
     for cbit in clob:
@@ -278,11 +299,16 @@ struct FusedC4Params {
                                      per category tip table, 9 LDS address of the first observation's tip slot, 10..17 the four
                                      root weights (lo, hi) */
 };
+
+template <int NC, int D>
+__device__ __forceinline__ void fused_run_program_cn(double (&lh)[NC], int (&esc)[NC], const FusedC4Params &p);
 """)
-for D in (4,):
+for nc, D in ((4, 4), (2, 4), (2, 8)):
+    set_nc(nc)
     text, outs, ins, clob = gen(D)
-    print("""/* runs the whole program for four categories of this lane's site: root expectations w . x_c and scale exponents out */
-__device__ __forceinline__ void fused_run_program_c4(double (&lh)[4], int (&esc)[4], const FusedC4Params &p)
+    print("""/* %d categories per pass, %d stack slots: root expectations w . x_c and scale exponents out */
+template <>
+__device__ __forceinline__ void fused_run_program_cn<%d, %d>(double (&lh)[%d], int (&esc)[%d], const FusedC4Params &p)
 {
     asm volatile(
 %s
@@ -290,5 +316,5 @@ __device__ __forceinline__ void fused_run_program_c4(double (&lh)[4], int (&esc)
         : %s
         : %s);
 }
-""" % (text, outs, ins, clob))
+""" % (nc, D, nc, D, nc, nc, text, outs, ins, clob))
 print("#endif")
