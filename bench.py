@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
     ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
     ap.add_argument("--fused-c", type=int, default=-1, help="rate categories per pass of the k = 4 assembly kernel (default: the engine's)")
+    ap.add_argument("--categories", type=int, default=0, help="override the number of Gamma categories (experiments; not the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
     ap.add_argument("--deriv-steps", type=int, default=3, help="steps of the edge-gradient leg (0 = skip)")
@@ -107,6 +108,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     wl = synth.Workload(args.config)
+    if args.categories and wl.mixture is not None:
+        wl.mixture = dict(wl.mixture, gamma_categories=args.categories)
+        wl.name += " [categories overridden: %d]" % args.categories
     S = args.sites or wl.default_S
     eng = E.Engine(local_rank)
     wl.setup_engine(eng)

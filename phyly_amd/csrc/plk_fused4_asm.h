@@ -27,7 +27,8 @@
  *   v[24:31] x0..x3  vector under construction      v[32:39] t0..t3 temporaries
  *   v40 address temp  v41 code of the next observation (raw)  v42 scale exponent  v43 temp
  *   v44 LDS address of this lane's code column   v45 nibble shift  v[46:53] prefetched tip value
- *   a[0:8D-1]  stack of D waiting vectors
+ *   D = 4: v[54:85] stack of 4 waiting vectors (operands of the multiply that pops them);
+ *   D = 8: a[0:63] stack of 8 waiting vectors (accumulation registers, moved through v[32:39])
  *   s[36:67] current P (transposed), FMA scalar operands
  *   s[68:75] current op block, s[76:83] next op block
  *   s[84:85] program pointer, s[86:87] matrix stream pointer, s[88:89] return address,
@@ -72,8 +73,33 @@
     PLK_ASM_PUSH(0, 0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_PUSH(1, 8, 9, 10, 11, 12, 13, 14, 15)     \
     PLK_ASM_PUSH(2, 16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_PUSH(3, 24, 25, 26, 27, 28, 29, 30, 31)
 
-#define PLK_ASM_SLOTS_D4_POP  PLK_ASM_POP_CHAIN4 "s_branch .Lpop3_%=\n" PLK_ASM_POP_BODY4
-#define PLK_ASM_SLOTS_D4_PUSH PLK_ASM_PUSH_CHAIN4 "s_branch .Lpush3_%=\n" PLK_ASM_PUSH_BODY4
+/* D <= 4: the stack lives in ordinary VGPRs v[54:85] (slot d = v[54 + 8d : 61 + 8d]).  A waiting vector is then an
+ * operand of the multiply that pops it: PUSH = 4 moves, POPMUL = 4 multiplies, against 8 + 8 accumulation-register
+ * moves + 4 multiplies with the AGPR stack -- 12 of 20 vector instructions per push / pop pair, ~12 % of all vector
+ * instructions of the kernel at BASELINE config 3 (the kernel is bound by vector issue, not by registers: 88 VGPRs
+ * still give 5 waves per SIMD). */
+#define PLK_ASM_VPOP(D_, A0, A1, B0, B1, C0, C1, E0, E1)                                  \
+    ".Lpop" #D_ "_%=:\n\t"                                                                \
+    "v_mul_f64 v[24:25], v[24:25], v[" #A0 ":" #A1 "]\n\t"                                \
+    "v_mul_f64 v[26:27], v[26:27], v[" #B0 ":" #B1 "]\n\t"                                \
+    "v_mul_f64 v[28:29], v[28:29], v[" #C0 ":" #C1 "]\n\t"                                \
+    "v_mul_f64 v[30:31], v[30:31], v[" #E0 ":" #E1 "]\n\t"                                \
+    "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_VPUSH(D_, A0, A1, B0, B1, C0, C1, E0, E1)                                 \
+    ".Lpush" #D_ "_%=:\n\t"                                                               \
+    "v_mov_b64 v[" #A0 ":" #A1 "], v[24:25]\n\t"                                          \
+    "v_mov_b64 v[" #B0 ":" #B1 "], v[26:27]\n\t"                                          \
+    "v_mov_b64 v[" #C0 ":" #C1 "], v[28:29]\n\t"                                          \
+    "v_mov_b64 v[" #E0 ":" #E1 "], v[30:31]\n\t"                                          \
+    "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_SLOTS_D4_POP  PLK_ASM_POP_CHAIN4 "s_branch .Lpop3_%=\n"                                   \
+    PLK_ASM_VPOP(0, 54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPOP(1, 62, 63, 64, 65, 66, 67, 68, 69)         \
+    PLK_ASM_VPOP(2, 70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPOP(3, 78, 79, 80, 81, 82, 83, 84, 85)
+#define PLK_ASM_SLOTS_D4_PUSH PLK_ASM_PUSH_CHAIN4 "s_branch .Lpush3_%=\n"                                 \
+    PLK_ASM_VPUSH(0, 54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPUSH(1, 62, 63, 64, 65, 66, 67, 68, 69)       \
+    PLK_ASM_VPUSH(2, 70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPUSH(3, 78, 79, 80, 81, 82, 83, 84, 85)
+#define PLK_CLOBBER_V54_85 "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", \
+    "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85"
 #define PLK_ASM_SLOTS_D8_POP                                                          \
     PLK_ASM_POP_CHAIN4                                                                \
     "s_cmp_eq_u32 s97, 3\n\ts_cbranch_scc1 .Lpop3_%=\n\t"                             \
@@ -290,7 +316,7 @@ __device__ __forceinline__ void fused_run_program_asm(double &x0, double &x1, do
     int x2lo = __double2loint(x2), x2hi = __double2hiint(x2), x3lo = __double2loint(x3), x3hi = __double2hiint(x3);
     if constexpr (D <= 4) {
         asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH)
-                     PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31);
+                     PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_V54_85);
     } else {
         asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH)
                      PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);

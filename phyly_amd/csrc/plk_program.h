@@ -484,11 +484,17 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
  *   header (8 ints): node, number of children, storage index of the node, rescaling slot or -1, has_data,
  *                    first CSR edge, marginal of the root wanted (first record only), 0
  *   child (4 ints):  node, tip slot or -1, PLK_UP_* flags, storage index (internal child) or -1
+ * An internal child whose own children (one or two) are all leaves is handled INSIDE this visit when no marginals are
+ * asked for (PLK_UP_INLINE): its forward vector is used while it is in registers and never stored, the node gets no
+ * visit of its own, and the child's fourth int is the offset (in rec) of a 12-int record placed after all visits:
+ *   node, has_data, rescaling slot or -1, number of leaves (1 or 2), first CSR edge,
+ *   leaf 0: node, tip slot, derivative wanted;  leaf 1: node, tip slot, derivative wanted;  0
  */
-enum { PLK_UP_WANT_D = 1, PLK_UP_WANT_F = 2, PLK_UP_WANT_M = 4, PLK_UP_STORE_F = 8 };
+enum { PLK_UP_WANT_D = 1, PLK_UP_WANT_F = 2, PLK_UP_WANT_M = 4, PLK_UP_STORE_F = 8, PLK_UP_INLINE = 16 };
 
 struct PlkUpVisits {
-    std::vector<int> rec;
+    std::vector<int> rec;              /* visit records, then the inline records */
+    size_t visit_ints = 0;             /* ints of rec taken by the visit records */
     int nvisits = 0;
     std::vector<int> kind, edge;       /* the matrix stream */
 };
@@ -506,21 +512,44 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
         return (wd ? PLK_UP_WANT_D : 0) | (wf ? PLK_UP_WANT_F : 0) | (wm ? PLK_UP_WANT_M : 0) | (!leaf ? PLK_UP_STORE_F : 0);
     };
     auto put = [&](int kind, int edge) { uv.kind.push_back(kind); uv.edge.push_back(edge); };
+    auto inlinable = [&](int b) {
+        const int d = ip[b + 1] - ip[b];
+        if (marg || d < 1 || d > 2) return false;
+        for (int idx = ip[b]; idx < ip[b + 1]; idx++) if (edge_tip[idx] < 0) return false;
+        return true;
+    };
+    std::vector<int> inl;                /* inline records, appended after the visits */
+    std::vector<size_t> fix;             /* positions in rec that hold an offset into inl */
     for (int u = 0; u < N; u++) {
         const int a = preorder[u];
         const int start = ip[a], deg = ip[a + 1] - start;
         if (deg == 0) continue;
+        if (u > 0 && inlinable(a)) continue;             /* handled inside its parent's visit */
         const int root_m = u == 0 && marg && (!node_mask || node_mask[a]);
         const int hdr[8] = {a, deg, node_int[a], node_scale[a], node_has_data[a] ? 1 : 0, start, root_m, 0};
         uv.rec.insert(uv.rec.end(), hdr, hdr + 8);
         for (int j = 0; j < deg; j++) {
             const int idx = start + j, b = ix[idx];
-            const int cr[4] = {b, edge_tip[idx], flags(idx, b), edge_tip[idx] >= 0 ? -1 : node_int[b]};
+            int fl = flags(idx, b), fourth = edge_tip[idx] >= 0 ? -1 : node_int[b];
+            if (edge_tip[idx] < 0 && inlinable(b)) {
+                fl = (fl & ~PLK_UP_STORE_F) | PLK_UP_INLINE | PLK_UP_WANT_F;
+                const int s0 = ip[b], db = ip[b + 1] - s0;
+                int r[12] = {b, node_has_data[b] ? 1 : 0, node_scale[b], db, s0, 0, 0, 0, 0, 0, 0, 0};
+                for (int q = 0; q < db; q++) {
+                    r[5 + 3 * q] = ix[s0 + q];
+                    r[6 + 3 * q] = edge_tip[s0 + q];
+                    r[7 + 3 * q] = deriv && (!edge_mask || edge_mask[s0 + q]) ? 1 : 0;
+                }
+                fourth = (int)inl.size();
+                fix.push_back(uv.rec.size() + 3);
+                inl.insert(inl.end(), r, r + 12);
+            }
+            const int cr[4] = {b, edge_tip[idx], fl, fourth};
             uv.rec.insert(uv.rec.end(), cr, cr + 4);
         }
         uv.nvisits++;
         for (int j = 0; j < deg; j++) {
-            const int idx = start + j, fl = flags(idx, ix[idx]);
+            const int idx = start + j, fl = flags(idx, ix[idx]) | (edge_tip[idx] < 0 && inlinable(ix[idx]) ? PLK_UP_WANT_F : 0);
             if (!(fl & (PLK_UP_WANT_D | PLK_UP_WANT_F))) continue;
             for (int j2 = 0; j2 < deg; j2++)
                 if (j2 != j && edge_tip[start + j2] < 0) put(0, start + j2);
@@ -528,6 +557,9 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
             if (fl & PLK_UP_WANT_F) put(2, idx);
         }
     }
+    uv.visit_ints = uv.rec.size();
+    for (size_t f : fix) uv.rec[f] += (int)uv.visit_ints;
+    uv.rec.insert(uv.rec.end(), inl.begin(), inl.end());
 }
 
 /* replays k_up_vec's walk over the records: every index in range, every stored forward vector written before it is
@@ -535,7 +567,7 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
 static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &uv, int nint_nodes, int ntips, int nscale_slots,
                                               bool deriv)
 {
-    std::vector<char> f_written(std::max(nint_nodes, 1), 0);
+    std::vector<char> f_written(std::max(nint_nodes, 1), 0), visited(N, 0), inlined(N, 0);
     size_t vp = 0, ms = 0;
     for (int v = 0; v < uv.nvisits; v++) {
         if (vp + 8 > uv.rec.size()) return "up visits: record overrun";
@@ -546,11 +578,24 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
         if (vp + 8 + 4 * (size_t)deg > uv.rec.size()) return "up visits: record overrun";
         if (v == 0) f_written[ai] = 1;       /* the root's forward vector is written first */
         if (!f_written[ai]) return plk_fmt("up visits: forward vector of node %ld read before it is written", a);
+        visited[a] = 1;
         const int *ch = h + 8;
         auto need = [&](int kind, int edge) -> bool { const bool ok = ms < uv.kind.size() && uv.kind[ms] == kind && uv.edge[ms] == edge; ms++; return ok; };
         for (int j = 0; j < deg; j++) {
             const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
-            if (b < 0 || b >= N || t < -1 || t >= ntips || (t < 0 && (bi < 0 || bi >= nint_nodes))) return plk_fmt("up visits: bad child in visit %ld", v);
+            if (b < 0 || b >= N || t < -1 || t >= ntips) return plk_fmt("up visits: bad child in visit %ld", v);
+            if (fl & PLK_UP_INLINE) {
+                /* the child's leaves are handled here: its record must lie behind the visits and be in range */
+                if (t >= 0 || (fl & PLK_UP_STORE_F) || !(fl & PLK_UP_WANT_F)) return plk_fmt("up visits: flags of an inline child in visit %ld", v);
+                if (bi < (long)uv.visit_ints || (size_t)bi + 12 > uv.rec.size()) return plk_fmt("up visits: inline record out of range in visit %ld", v);
+                const int *q = &uv.rec[bi];
+                if (q[0] != b || q[2] < -1 || q[2] >= nscale_slots || q[3] < 1 || q[3] > 2 || q[4] < 0 || q[4] + q[3] > E) return plk_fmt("up visits: bad inline record in visit %ld", v);
+                for (int l = 0; l < q[3]; l++)
+                    if (q[5 + 3 * l] < 0 || q[5 + 3 * l] >= N || q[6 + 3 * l] < 0 || q[6 + 3 * l] >= ntips) return plk_fmt("up visits: bad inline leaf in visit %ld", v);
+                inlined[b] = 1;
+                continue;
+            }
+            if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up visits: bad child in visit %ld", v);
             if (((fl & PLK_UP_STORE_F) != 0) != (t < 0) || (t < 0 && !(fl & PLK_UP_WANT_F))) return plk_fmt("up visits: flags of an internal child in visit %ld", v);
             if (!deriv && (fl & PLK_UP_WANT_D)) return "up visits: derivative flag without a derivative pass";
         }
@@ -565,7 +610,8 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
         for (int j = 0; j < deg; j++) if (ch[4 * j + 2] & PLK_UP_STORE_F) f_written[ch[4 * j + 3]] = 1;
         vp += 8 + 4 * (size_t)deg;
     }
-    if (vp != uv.rec.size()) return "up visits: trailing records";
+    if (vp != uv.visit_ints) return "up visits: trailing records";
+    for (int a = 0; a < N; a++) if (visited[a] && inlined[a]) return plk_fmt("up visits: node %ld is both visited and inlined", a);
     if (ms != uv.kind.size()) return "up visits: matrix stream not consumed";
     for (size_t i = 0; i < uv.edge.size(); i++) if (uv.edge[i] < 0 || uv.edge[i] >= E || uv.kind[i] < 0 || uv.kind[i] > 2) return "up visits: bad stream entry";
     return "";

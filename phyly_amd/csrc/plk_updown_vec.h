@@ -333,6 +333,46 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                         else udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, lb);
                         UDV_OUT_M(b, fb, lb);
                     }
+                    if (DERIV && (fl & PLK_UP_INLINE)) {
+                        /* the child's own children are leaves: their edge forms are finished here, while the child's
+                         * forward vector is in registers (it is never stored, the child has no visit of its own) */
+                        const PLK_AS4 int *q = vis + bi;
+                        if (q[1]) {
+                            double bv[K];
+                            udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, bv);
+#pragma unroll
+                            for (int i = 0; i < K; i++) fb[i] *= bv[i];
+                        }
+                        if (q[2] >= 0) {
+                            const double sc = a.SC[((size_t)q[2] * a.C + c) * n + slc];
+#pragma unroll
+                            for (int i = 0; i < K; i++) fb[i] *= sc;
+                        }
+                        const int nl = q[3], le0 = q[4];
+                        const int cd0 = a.codes[(size_t)q[5] * a.Spad + sg];
+                        const int cd1 = nl == 2 ? a.codes[(size_t)q[8] * a.Spad + sg] : 0;
+                        if (q[7]) {
+                            double y[K], d = 0.0;
+                            udv_gather<K>(dtipc + ((size_t)q[6] * a.nchar + cd0) * K, y);
+                            if (nl == 2) {
+                                double m[K];
+                                udv_gather<K>(tipc + ((size_t)q[9] * a.nchar + cd1) * K, m);
+#pragma unroll
+                                for (int i = 0; i < K; i++) y[i] *= m[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < K; i++) d = fma(fb[i], y[i], d);
+                            UDV_OUT_D(le0, pc * d);
+                        }
+                        if (nl == 2 && q[10]) {
+                            double y[K], m[K], d = 0.0;
+                            udv_gather<K>(dtipc + ((size_t)q[9] * a.nchar + cd1) * K, y);
+                            udv_gather<K>(tipc + ((size_t)q[6] * a.nchar + cd0) * K, m);
+#pragma unroll
+                            for (int i = 0; i < K; i++) d = fma(fb[i] * m[i], y[i], d);
+                            UDV_OUT_D(le0 + 1, pc * d);
+                        }
+                    }
                 }
             }
         }

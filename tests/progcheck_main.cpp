@@ -76,6 +76,28 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
             }
         }
     }
+    /* visit records + matrix stream of the vector up pass, for every kind of query and with random masks */
+    {
+        std::vector<int> emask(E > 0 ? E : 1), nmask(N);
+        unsigned lcg = 12345u + (unsigned)N * 7919u;
+        for (int e = 0; e < E; e++) { lcg = lcg * 1664525u + 1013904223u; emask[e] = (lcg >> 24) % 3 != 0; }
+        for (int a = 0; a < N; a++) { lcg = lcg * 1664525u + 1013904223u; nmask[a] = (lcg >> 24) % 3 != 0; }
+        const int modes[3][2] = {{1, 0}, {0, 1}, {1, 1}};
+        for (int md = 0; md < 3; md++)
+            for (int masked = 0; masked < 2; masked++) {
+                PlkUpVisits uv;
+                plk_up_visits_build(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), edge_tip.data(), node_int.data(),
+                                    node_scale.data(), modes[md][0] != 0, modes[md][1] != 0, masked ? emask.data() : nullptr,
+                                    masked ? nmask.data() : nullptr, uv);
+                bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, modes[md][0] != 0);
+                if (!bad.empty()) return "up visits (deriv " + std::to_string(modes[md][0]) + ", marg " + std::to_string(modes[md][1]) + "): " + bad;
+                if (md == 0 && !masked && !uv.kind.empty()) {      /* negative control: a dropped matrix must be noticed */
+                    PlkUpVisits u2 = uv;
+                    u2.kind.pop_back(); u2.edge.pop_back();
+                    if (plk_up_visits_check(N, E, u2, nin, ntips, nsc, true).empty()) return "negative control: short matrix stream accepted";
+                }
+            }
+    }
     if (pg.slots_needed > PLK_FUSED_SLOTS) return "";
     PlkFused fu;
     plk_fused_build(N, pg, fu);
