@@ -80,7 +80,6 @@ def main():
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the config's S)")
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
     ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
-    ap.add_argument("--fused-c", type=int, default=-1, help="rate categories per pass of the k = 4 assembly kernel (default: the engine's)")
     ap.add_argument("--categories", type=int, default=0, help="override the number of Gamma categories (experiments; not the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
@@ -118,8 +117,6 @@ def main():
         eng.set_option(E.OPT_FORCE_GENERIC, 1)
     if args.fused_ns:
         eng.set_option(E.OPT_FUSED_NS, args.fused_ns)
-    if args.fused_c >= 0:
-        eng.set_option(E.OPT_FUSED_C4, args.fused_c)
 
     # resident patterns: this rank's block of the alignment, generated on the GPU
     chunk = 1 << 20
@@ -214,7 +211,7 @@ def main():
         flops = alg["W_ll"] * S / kern_s
         kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
         if kernel_kind == 1:
-            kname = {1: "k_ll_fused4_asm", 2: "k_ll_fused4_cn<4", 3: "k_ll_fused4", 4: "k_ll_fused4_cn<2"}.get(eng.info(E.INFO_LL_VARIANT), kname)
+            kname = {1: "k_ll_fused4_asm", 3: "k_ll_fused4"}.get(eng.info(E.INFO_LL_VARIANT), kname)
         # HBM bytes per launch from the PMC passes of the guide's recipe (profiles/traffic_cfgN.json, written by
         # tools/pmc_traffic.py from rocprofv3 --pmc runs of this kernel).  Only used when the file was measured on the
         # kernel that ran here, at this site count; anything else is reported as null rather than a stale number.

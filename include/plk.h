@@ -205,9 +205,7 @@ enum {
     PLK_INFO_LAST_LL_TOTAL_NS = 4,  /* HIP-event time of the last whole plk_ll device work */
     PLK_INFO_LL_KERNEL_NS_SUM = 5,  /* HIP-event time of the traversal kernels of all ll evaluations since this item was */
     PLK_INFO_LL_KERNEL_COUNT = 6,   /* last read, and their number (reading waits for queued evaluations, then resets) */
-    PLK_INFO_LL_VARIANT = 7         /* fused k = 4 kernel of the last evaluation: 1 assembly interpreter, one rate category per pass;
-                                       2 assembly interpreter, four categories per pass; 3 C++ interpreter; 4 assembly interpreter,
-                                       two categories per pass */
+    PLK_INFO_LL_VARIANT = 7         /* fused k = 4 kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter */
 };
 
 /* force the generic (HBM-resident partials) traversal even where the fused
@@ -215,8 +213,6 @@ enum {
 int plk_set_option(plk_engine *h, int option, long value);
 enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PER_LANE = 2 /* 0 auto, 1, 2 */,
        PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */,
-       PLK_OPT_FUSED_C4 = 5 /* rate categories the k = 4 assembly kernel carries per pass of the traversal program when their number
-                               divides: 2 (default), 4 (stack <= 4 slots), 0 / 1: one category per pass */,
        PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
                            33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */ };
 

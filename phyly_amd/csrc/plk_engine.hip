@@ -127,8 +127,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_fused_c4 = 2;
-    int fused_nc = 1;                    /* rate categories per pass the fused formats are laid out for (1, 2 or 4) */
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
@@ -229,7 +228,6 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 struct ExpmPost {
     const int *edge_slot;      /* [2][E]: matrix index of the edge or -1 | tip slot of the edge or -1; null: no post */
     int nmat1, ntips1, nchar;  /* matrices / tip slots per category (incl. the spare / pseudo one), definitions */
-    int nc;                    /* matrix stream [group of nc categories][matrix][category in group][16] (k_ll_fused4_cn) */
     const double *defs;        /* [nchar][4] */
     double *PS, *tip;
 };
@@ -340,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
             for (int idx = threadIdx.x; idx < 16; idx += blockDim.x) {
                 const int j = idx >> 2, i = idx & 3;
                 const double v = O[i * 4 + j].hi;
-                const size_t slot = ((size_t)(c / post.nc) * post.nmat1 + mi) * post.nc + (c % post.nc);
+                const size_t slot = (size_t)c * post.nmat1 + mi;
                 post.PS[slot * 16 + idx] = v < 0 ? 0.0 : v;
             }
         if (t >= 0)
@@ -504,7 +502,6 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
-#include "plk_fused4_c4.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_vec.h"
@@ -1091,7 +1088,6 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
-    if (option == PLK_OPT_FUSED_C4) { h->opt_fused_c4 = value; h->fmt_dirty = true; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1199,7 +1195,7 @@ static int run_expm(plk_engine *h, bool post = false)
     post = post && k == 4 && h->fmt_kind == 1 && !h->fmt_dirty && h->d_edge_slot;
     if (post) {
         ep.edge_slot = h->d_edge_slot; ep.nmat1 = (int)h->mat_edge.size() + 1; ep.ntips1 = (int)h->tip_edge.size() + 1;
-        ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip; ep.nc = h->fused_nc;
+        ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip;
     }
     hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
@@ -1435,14 +1431,6 @@ static int upload_formats(plk_engine *h, long kind)
         if ((rc = dev_upload(h, &h->d_edge_slot, em.data(), em.size()))) return rc;
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * (h->mat_edge.size() + 1) * 16))) return rc;
         if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * 4))) return rc;
-        /* several categories per pass (k_ll_fused4_cn) when their number divides, the stack fits and the tip tables of
-         * the group fit in LDS: PLK_OPT_FUSED_C4 = 4 asks for four (stack <= 4 slots), >= 2 for two (stack <= 8) */
-        h->fused_nc = 1;
-        if (h->opt_fused_asm && h->fu.asm_ok && fused_sites_per_lane(h) == 1) {
-            const int rb = h->nchar <= 16 ? PLK_TILE / 2 : PLK_TILE;
-            if (h->opt_fused_c4 >= 4 && h->C % 4 == 0 && h->slots_needed <= 4 && plk_fused_lds_bytes(h->pg, h->nchar, rb, 4) <= PLK_LDS_LIMIT) h->fused_nc = 4;
-            else if (h->opt_fused_c4 >= 2 && h->C % 2 == 0 && h->slots_needed <= 8 && plk_fused_lds_bytes(h->pg, h->nchar, rb, 2) <= PLK_LDS_LIMIT) h->fused_nc = 2;
-        }
         /* K1 fills the stream and the tip slots of the edges; the spare matrices stay zero and the pseudo tip slot
          * (raw definitions) is written here */
         HIPCHK(h, hipMemsetAsync(h->d_PS, 0, (size_t)h->C * (h->mat_edge.size() + 1) * 16 * sizeof(double), h->stream));
@@ -1571,23 +1559,18 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.root_mode = h->root_mode; a.first_row = h->fu.first_row;
         const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
         const bool use_asm = NS == 1 && h->fu.asm_ok && h->opt_fused_asm;
-        if (!use_asm && h->fused_nc != 1) { h->err = "internal: fused formats are laid out for several categories per pass"; return PLK_E_ARG; }
         const int D = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : 16);
         if (use_asm) {
             FusedAsmArgs aa;
             aa.f = a; aa.words = h->d_words;
             aa.first_tip = h->fu.asm_first_tip; aa.first_row = h->fu.asm_first_row; aa.second_row = h->fu.asm_second_row;
             aa.pack4 = h->nchar <= 16 ? 1 : 0;
-            const int ncat = h->fused_nc;
-            const size_t lds_asm = plk_fused_lds_bytes(h->pg, h->nchar, aa.pack4 ? PLK_TILE / 2 : PLK_TILE, ncat);
+            const size_t lds_asm = plk_fused_lds_bytes(h->pg, h->nchar, aa.pack4 ? PLK_TILE / 2 : PLK_TILE);
             /* replay the interpreter's fetches and LDS addresses on the host before launching (plk_program.h) */
-            const std::string bad = plk_fused_check_asm(h->N, h->pg, h->fu, h->nchar, D, aa.pack4, lds_asm, ncat);
+            const std::string bad = plk_fused_check_asm(h->N, h->pg, h->fu, h->nchar, D, aa.pack4, lds_asm);
             if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
-            h->info_ll_variant = ncat == 4 ? 2 : (ncat == 2 ? 4 : 1);
-            if (ncat == 4) hipLaunchKernelGGL((k_ll_fused4_cn<4, 4>), dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-            else if (ncat == 2 && D == 4) hipLaunchKernelGGL((k_ll_fused4_cn<2, 4>), dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-            else if (ncat == 2) hipLaunchKernelGGL((k_ll_fused4_cn<2, 8>), dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
-            else if (D == 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
+            h->info_ll_variant = 1;
+            if (D == 4) hipLaunchKernelGGL(k_ll_fused4_asm<4>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
             else hipLaunchKernelGGL(k_ll_fused4_asm<8>, dim3(grid), dim3(PLK_TILE), lds_asm, h->stream, aa);
         } else {
             h->info_ll_variant = 3;

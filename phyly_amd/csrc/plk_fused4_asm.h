@@ -346,17 +346,32 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedAsmArgs aa)
     const long s = tile0 + tid;
     const int row_bytes = aa.pack4 ? PLK_TILE / 2 : PLK_TILE;
     {
-        /* each thread moves 4 codes of one row: one dword in, one dword (or one 16-bit pair) out */
-        const int ndw = a.nobs * (PLK_TILE / 4);
-        for (int idx = tid; idx < ndw; idx += PLK_TILE) {
-            const int row = idx >> 6, col = idx & 63;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad + tile0);
-            const uint32_t q = src[col];
-            if (aa.pack4) {
-                const uint32_t packed = (q & 0xf) | ((q >> 4) & 0xf0) | ((q >> 8) & 0xf00) | ((q >> 12) & 0xf000);
-                reinterpret_cast<uint16_t *>(code_lds)[row * (PLK_TILE / 4) + col] = (uint16_t)packed;
-            } else {
-                reinterpret_cast<uint32_t *>(code_lds)[idx] = q;
+        /* Staged code rows: wave w takes rows w, w + 4, ...; a lane moves 4 codes of a row (one dword in, one dword or
+         * one 16-bit pair out).  The row's node comes through a scalar load and eight rows are requested before the first
+         * one is stored: written as one load per loop iteration with the node looked up by the lane, the compiler
+         * serialised two dependent global loads per row -- 25 round trips per tile, ~20 us of the 57 us a tile takes
+         * for one rate category (profiles/r02_exp_headline_kernel_variants.json: 1.73 ms for one category against
+         * 1.27 ms per category with four). */
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const PLK_AS4 int *obs = as_uniform(a.obs_nodes);
+        for (int r0 = wave; r0 < a.nobs; r0 += 32) {
+            uint32_t q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + 4 * u;
+                q[u] = row < a.nobs ? reinterpret_cast<const uint32_t *>(a.codes + (size_t)obs[row] * a.Spad + tile0)[lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + 4 * u;
+                if (row < a.nobs) {
+                    if (aa.pack4) {
+                        const uint32_t packed = (q[u] & 0xf) | ((q[u] >> 4) & 0xf0) | ((q[u] >> 8) & 0xf00) | ((q[u] >> 12) & 0xf000);
+                        reinterpret_cast<uint16_t *>(code_lds)[row * (PLK_TILE / 4) + lane] = (uint16_t)packed;
+                    } else {
+                        reinterpret_cast<uint32_t *>(code_lds)[row * (PLK_TILE / 4) + lane] = q[u];
+                    }
+                }
             }
         }
     }
@@ -380,9 +395,17 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedAsmArgs aa)
     for (int c = 0; c < a.C; c++) {
         __syncthreads();
         {
+            /* tip table of the category: four 16-byte loads in flight per lane */
             const double2 *src = reinterpret_cast<const double2 *>(a.tip + (size_t)c * tip_doubles);
             double2 *dst = reinterpret_cast<double2 *>(tip_lds);
-            for (int idx = tid; idx < tip_doubles / 2; idx += PLK_TILE) dst[idx] = src[idx];
+            const int n2 = tip_doubles / 2;
+            for (int i0 = tid; i0 < n2; i0 += 4 * PLK_TILE) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = i0 + u * PLK_TILE < n2 ? src[i0 + u * PLK_TILE] : double2{0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (i0 + u * PLK_TILE < n2) dst[i0 + u * PLK_TILE] = v[u];
+            }
         }
         __syncthreads();
         double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;

@@ -309,9 +309,7 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
     if (fu.words.size() % 8 != 0 || (int)fu.words.size() < ((nops + 1 + 7) / 8) * 8 + 8) return "asm program: word buffer too short";
     const size_t row_bytes = pack4 ? PLK_TILE / 2 : PLK_TILE;
     const size_t tip_bytes = (size_t)ntips1 * nchar * 32, code_bytes = (size_t)nobs * row_bytes;
-    /* k_ll_fused4_c4 keeps the tip tables of ncat_lds = 4 categories in LDS; the per-category addresses are the
-     * single-table ones plus a multiple of tip_bytes */
-    if (ncat_lds != 1 && ncat_lds != 2 && ncat_lds != 4) return "asm program: categories per pass";
+    if (ncat_lds < 1) return "asm program: categories per pass";
     if ((size_t)ncat_lds * tip_bytes + code_bytes > lds_bytes_launched) return "asm program: LDS image larger than the launch's dynamic LDS";
     if (lds_bytes_launched > PLK_LDS_LIMIT) return "asm program: dynamic LDS above the limit";
     if (nobs < 1) return "asm program: no observation rows";
@@ -530,7 +528,8 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
         uv.rec.insert(uv.rec.end(), hdr, hdr + 8);
         for (int j = 0; j < deg; j++) {
             const int idx = start + j, b = ix[idx];
-            int fl = flags(idx, b), fourth = edge_tip[idx] >= 0 ? -1 : node_int[b];
+            int fl = flags(idx, b), second = edge_tip[idx];
+            const int fourth = edge_tip[idx] >= 0 ? -1 : node_int[b];
             if (edge_tip[idx] < 0 && inlinable(b)) {
                 fl = (fl & ~PLK_UP_STORE_F) | PLK_UP_INLINE | PLK_UP_WANT_F;
                 const int s0 = ip[b], db = ip[b + 1] - s0;
@@ -540,11 +539,11 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
                     r[6 + 3 * q] = edge_tip[s0 + q];
                     r[7 + 3 * q] = deriv && (!edge_mask || edge_mask[s0 + q]) ? 1 : 0;
                 }
-                fourth = (int)inl.size();
-                fix.push_back(uv.rec.size() + 3);
+                second = (int)inl.size();            /* becomes -2 - (visit_ints + offset) below */
+                fix.push_back(uv.rec.size() + 1);
                 inl.insert(inl.end(), r, r + 12);
             }
-            const int cr[4] = {b, edge_tip[idx], fl, fourth};
+            const int cr[4] = {b, second, fl, fourth};
             uv.rec.insert(uv.rec.end(), cr, cr + 4);
         }
         uv.nvisits++;
@@ -558,7 +557,7 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
         }
     }
     uv.visit_ints = uv.rec.size();
-    for (size_t f : fix) uv.rec[f] += (int)uv.visit_ints;
+    for (size_t f : fix) uv.rec[f] = -2 - (uv.rec[f] + (int)uv.visit_ints);
     uv.rec.insert(uv.rec.end(), inl.begin(), inl.end());
 }
 
@@ -583,19 +582,20 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
         auto need = [&](int kind, int edge) -> bool { const bool ok = ms < uv.kind.size() && uv.kind[ms] == kind && uv.edge[ms] == edge; ms++; return ok; };
         for (int j = 0; j < deg; j++) {
             const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
-            if (b < 0 || b >= N || t < -1 || t >= ntips) return plk_fmt("up visits: bad child in visit %ld", v);
+            if (b < 0 || b >= N || t >= ntips || ((t < -1) != ((fl & PLK_UP_INLINE) != 0))) return plk_fmt("up visits: bad child in visit %ld", v);
+            if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up visits: bad storage index in visit %ld", v);
             if (fl & PLK_UP_INLINE) {
                 /* the child's leaves are handled here: its record must lie behind the visits and be in range */
-                if (t >= 0 || (fl & PLK_UP_STORE_F) || !(fl & PLK_UP_WANT_F)) return plk_fmt("up visits: flags of an inline child in visit %ld", v);
-                if (bi < (long)uv.visit_ints || (size_t)bi + 12 > uv.rec.size()) return plk_fmt("up visits: inline record out of range in visit %ld", v);
-                const int *q = &uv.rec[bi];
+                const long off = -2 - (long)t;
+                if ((fl & PLK_UP_STORE_F) || !(fl & PLK_UP_WANT_F)) return plk_fmt("up visits: flags of an inline child in visit %ld", v);
+                if (off < (long)uv.visit_ints || (size_t)off + 12 > uv.rec.size()) return plk_fmt("up visits: inline record out of range in visit %ld", v);
+                const int *q = &uv.rec[off];
                 if (q[0] != b || q[2] < -1 || q[2] >= nscale_slots || q[3] < 1 || q[3] > 2 || q[4] < 0 || q[4] + q[3] > E) return plk_fmt("up visits: bad inline record in visit %ld", v);
                 for (int l = 0; l < q[3]; l++)
                     if (q[5 + 3 * l] < 0 || q[5 + 3 * l] >= N || q[6 + 3 * l] < 0 || q[6 + 3 * l] >= ntips) return plk_fmt("up visits: bad inline leaf in visit %ld", v);
                 inlined[b] = 1;
                 continue;
             }
-            if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up visits: bad child in visit %ld", v);
             if (((fl & PLK_UP_STORE_F) != 0) != (t < 0) || (t < 0 && !(fl & PLK_UP_WANT_F))) return plk_fmt("up visits: flags of an internal child in visit %ld", v);
             if (!deriv && (fl & PLK_UP_WANT_D)) return "up visits: derivative flag without a derivative pass";
         }

@@ -183,12 +183,24 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int4
     const long slc = valid ? sl : a.n - 1;
     const size_t n = (size_t)a.n;
     {
-        /* rows are padded to Spad (a multiple of 1024) and chunks start at multiples of 256 */
+        /* rows are padded to Spad (a multiple of 1024) and chunks start at multiples of 256; wave w stages rows w, w + 4,
+         * ... with the node looked up through a scalar load and eight rows in flight (see k_ll_fused4_asm) */
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const PLK_AS4 int *obs = as_uniform(obs_nodes);
         uint32_t *dst = reinterpret_cast<uint32_t *>(ud4_codes);
-        for (int idx = tid; idx < nobs * (UD4_BLOCK / 4); idx += UD4_BLOCK) {
-            const int row = idx / (UD4_BLOCK / 4), col = idx - row * (UD4_BLOCK / 4);
-            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)obs_nodes[row] * a.Spad + a.s0 +
-                                                          (size_t)blockIdx.x * UD4_BLOCK)[col];
+        for (int r0 = wave; r0 < nobs; r0 += 32) {
+            uint32_t q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + 4 * u;
+                q[u] = row < nobs ? reinterpret_cast<const uint32_t *>(a.codes + (size_t)obs[row] * a.Spad + a.s0 +
+                                                                         (size_t)blockIdx.x * UD4_BLOCK)[lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int row = r0 + 4 * u;
+                if (row < nobs) dst[row * (UD4_BLOCK / 4) + lane] = q[u];
+            }
         }
     }
     __syncthreads();

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
 /*
  * Up pass.  visits: for every internal node in BFS order
  *   header (8 ints): node a, number of children, storage index of a, rescaling slot or -1, has_data, 0, 0, 0
- *   per child (4 ints): child node b, tip slot or -1, UDV_* flags, storage index of b (internal) or -1;
+ *   per child (4 ints): child node b, tip slot (>= 0) / -1 internal / <= -2 internal and handled inline, UDV_* flags,
+ *   storage index of b (internal) or -1;
  *   children with a CSR edge index idx = first_edge + position: the header's int [5] holds first_edge.
  * Matrix stream MS (per category): the matrices in the order the visit code below consumes them:
  *   per child in order: for every internal sibling PT(sibling); internal child with WANT_D: DT(child); WANT_F: PN(child)
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (DERIV && (fl & PLK_UP_INLINE)) {
                         /* the child's own children are leaves: their edge forms are finished here, while the child's
                          * forward vector is in registers (it is never stored, the child has no visit of its own) */
-                        const PLK_AS4 int *q = vis + bi;
+                        const PLK_AS4 int *q = vis + (-2 - t);       /* the child's inline record (plk_program.h) */
                         if (q[1]) {
                             double bv[K];
                             udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, bv);

@@ -10,7 +10,7 @@ if [ "$1" = "--timeout" ]; then limit="$2"; shift 2; fi
 mkdir -p gpurun_out
 log="gpurun_out/$name.log"
 echo "== step $name: $* (limit ${limit}s)" | tee "$log"
-export PYTHONUNBUFFERED=1 AMD_LOG_LEVEL=${AMD_LOG_LEVEL:-0}
+export PYTHONUNBUFFERED=1 AMD_LOG_LEVEL=${AMD_LOG_LEVEL:-1}     # level 1 keeps the runtime's own error lines (e.g. "Memory access fault by GPU ...")
 timeout -k 10 "$limit" "$@" >> "$log" 2>&1
 rc=$?
 echo "$rc" > "gpurun_out/$name.rc"
