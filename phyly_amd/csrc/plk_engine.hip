@@ -117,7 +117,7 @@ struct plk_engine {
     size_t u4pack_cap = 0, u4tip_cap = 0;
     double *d_stage = nullptr; size_t stage_cap = 0;   /* transposed per-site outputs on their way to the host */
     double *d_uvmat = nullptr; size_t uvmat_cap = 0;   /* vector down / up passes: PT and the up-pass matrix stream */
-    int mfma_first_slot = -1, mfma_first_row = 0;
+    int mfma_first_slot = -1, mfma_first_row = 0, vec_second_row = 0;
     size_t ps_cap = 0, tip_cap = 0;
 
     /* workspaces */
@@ -148,6 +148,16 @@ static bool plk_live(const plk_engine *h)
     return !g_exiting && g_live.count(h) != 0;
 }
 
+/* HIPCHKC: the same inside a function that owns per-call device memory through a local `cleanup` lambda */
+#define HIPCHKC(h, call)                                                           \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);         \
+            cleanup();                                                             \
+            return PLK_E_DEVICE;                                                   \
+        }                                                                          \
+    } while (0)
 #define HIPCHK(h, call)                                                            \
     do {                                                                           \
         hipError_t e_ = (call);                                                    \
@@ -1454,6 +1464,13 @@ static int upload_formats(plk_engine *h, long kind)
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * std::max(nops, 1) * h->K * h->K))) return rc;
         if (kind == 4) {
             if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * h->K))) return rc;
+            /* vector program: observation ops chained two ahead (value of the next op, code of the one after) */
+            PlkChain ch;
+            plk_chain_build(h->N, h->pg, 3, h->indices.data(), nullptr, nullptr, nullptr, ch);
+            const std::string bad = plk_chain_check(h->N, h->pg, ch, 3, INT_MAX, 0, 0, 0, 0, 0);
+            if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+            h->mfma_first_slot = ch.first_slot; h->mfma_first_row = ch.first_row; h->vec_second_row = ch.second_row;
+            if ((rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(ch.ops.data()), ch.ops.size()))) return rc;
         } else if (kind == 3) {
             const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
             std::vector<double> rwd((size_t)4 * R, 0.0);
@@ -1595,7 +1612,8 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * K * S))) return rc;
         VecArgs a;
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.C = h->C; a.nops = nops; a.ntips = ntips; a.nchar = h->nchar;
-        a.root_mode = h->root_mode; a.ops = h->d_ops; a.PS = h->d_PS; a.tip = h->d_tip; a.codes = h->d_codes;
+        a.root_mode = h->root_mode; a.ops = h->d_mops; a.PS = h->d_PS; a.tip = h->d_tip; a.codes = h->d_codes;
+        a.obs_nodes = h->d_obs_nodes; a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row; a.second_row = h->vec_second_row;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
         a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         if (K == 16) hipLaunchKernelGGL(k_ll_vec<16>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
@@ -1800,9 +1818,6 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     int nsc = 0;
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
-    int *d_et = nullptr, *d_ei = nullptr, *d_ni = nullptr, *d_te = nullptr, *d_emask = nullptr, *d_nmask = nullptr;
-    int *d_has = nullptr, *d_ns = nullptr, *d_obsm = nullptr;
-    int4 *d_dops = nullptr;
     /* program of the depth-first down pass (k_down_fused_mfma) */
     PlkChain dch;
     plk_chain_build(N, h->pg, 2, h->indices.data(), node_int.data(), edge_int.data(), node_scale.data(), dch);
@@ -1812,22 +1827,32 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     }
     const std::vector<plk_op4> &dops = dch.ops;
     const int nslots_m = std::max(h->slots_needed, 1);
-    double *d_fP = nullptr, *d_fPT = nullptr, *d_fD = nullptr, *d_tipd = nullptr, *d_dtip = nullptr, *d_rwd = nullptr;
-    auto cleanup = [&]() {
-        void *ps[] = {d_et, d_ei, d_ni, d_te, d_emask, d_nmask, d_has, d_ns, d_obsm, d_dops, d_fP, d_fPT, d_fD, d_tipd, d_dtip, d_rwd};
-        for (void *p : ps) if (p) (void)hipFree(p);
-    };
-    const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
-    if ((rc = dev_upload(h, &d_et, edge_tip.data(), (size_t)E)) || (rc = dev_upload(h, &d_ei, edge_int.data(), (size_t)E)) ||
-        (rc = dev_upload(h, &d_ni, node_int.data(), (size_t)N)) || (rc = dev_upload(h, &d_te, te.data(), te.size())) ||
-        (rc = dev_upload(h, &d_rwd, rwd.data(), rwd.size())) || (rc = dev_upload(h, &d_ns, node_scale.data(), (size_t)N)) ||
-        (rc = dev_upload(h, &d_dops, reinterpret_cast<const int4 *>(dops.data()), dops.size())) || (rc = dev_upload(h, &d_obsm, h->obs_nodes.data(), h->obs_nodes.size())) ||
-        (rc = dev_alloc(h, &d_fP, nfr)) || (rc = dev_alloc(h, &d_fPT, nfr)) || (rc = dev_alloc(h, &d_fD, nfr)) ||
-        (rc = dev_alloc(h, &d_tipd, ntab)) || (rc = dev_alloc(h, &d_dtip, ntab))) { cleanup(); return rc; }
-    if (edge_mask && (rc = dev_upload(h, &d_emask, edge_mask, (size_t)E))) { cleanup(); return rc; }
-    if (node_mask && (rc = dev_upload(h, &d_nmask, node_mask, (size_t)N))) { cleanup(); return rc; }
+    auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
-    { std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end()); if ((rc = dev_upload(h, &d_has, hd.data(), (size_t)N))) { cleanup(); return rc; } }
+    /* the call's integer tables, one upload: [ops (16-byte aligned first)][edge_tip][edge_int][node_int][tip edges][node_scale]
+     * [obs nodes][has_data][edge mask][node mask] */
+    std::vector<int> pack;
+    auto put = [&](const int *src, size_t n) { const size_t o = pack.size(); pack.insert(pack.end(), src, src + n); while (pack.size() & 3) pack.push_back(0); return o; };
+    const size_t o_ops = put(reinterpret_cast<const int *>(dops.data()), dops.size() * 4);
+    const size_t o_et = put(edge_tip.data(), (size_t)E), o_ei = put(edge_int.data(), (size_t)E), o_ni = put(node_int.data(), (size_t)N);
+    const size_t o_te = put(te.data(), te.size()), o_ns = put(node_scale.data(), (size_t)N);
+    const size_t o_obs = put(h->obs_nodes.data(), h->obs_nodes.size());
+    std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end());
+    const size_t o_has = put(hd.data(), (size_t)N);
+    const size_t o_em = edge_mask ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
+    const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
+    if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4)) ||
+        (rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, 2 * ntab + rwd.size())) ||
+        (rc = dev_reserve(h, &h->d_uvmat, &h->uvmat_cap, 3 * nfr))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_u4pack, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_u4tip + 2 * ntab, rwd.data(), rwd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      /* pack and rwd are locals */
+    int *pk = h->d_u4pack;
+    const int4 *d_dops = reinterpret_cast<const int4 *>(pk + o_ops);
+    const int *d_et = pk + o_et, *d_ei = pk + o_ei, *d_ni = pk + o_ni, *d_te = pk + o_te, *d_ns = pk + o_ns, *d_obsm = pk + o_obs, *d_has = pk + o_has;
+    const int *d_emask = edge_mask ? pk + o_em : nullptr, *d_nmask = node_mask ? pk + o_nm : nullptr;
+    double *d_fP = h->d_uvmat, *d_fPT = d_fP + nfr, *d_fD = d_fPT + nfr;
+    double *d_tipd = h->d_u4tip, *d_dtip = d_tipd + ntab, *d_rwd = d_dtip + ntab;
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_P, d_fP);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 1, h->d_P, d_fPT);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, d_M, d_fD);
@@ -2089,12 +2114,12 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
     /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
     PlkChain ch;
-    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
+    plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
     PlkUpVisits uv;
     plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
                         node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
     {
-        std::string bad = plk_chain_check(N, h->pg, ch, 1, INT_MAX, nin, nie, nsc, 0, 0);
+        std::string bad = plk_chain_check(N, h->pg, ch, 3, INT_MAX, nin, nie, nsc, 0, 0);
         if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
@@ -2148,6 +2173,7 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         a.S = S; a.Spad = h->Spad; a.s0 = s0; a.n = n;
         a.N = N; a.E = E; a.k = k; a.C = C; a.nchar = h->nchar; a.ntips = ntips; a.root_mode = h->root_mode; a.dzero = dzero;
         a.ops = reinterpret_cast<const int4 *>(b + o_ops); a.nops = (int)h->ops.size(); a.root_int = node_int[h->preorder[0]];
+        a.first_slot = ch.first_slot; a.first_row = ch.first_row; a.second_row = ch.second_row;
         a.PT = d_PT; a.tip = d_tipv; a.dtip = d_dtipv; a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w;
         a.visits = b + o_vis; a.nvisits = uv.nvisits; a.MS = d_MS; a.nstream = nstream;
         double *p = h->d_work;
@@ -2269,8 +2295,8 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * k * n;
-        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
-        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
+        if (deriv) HIPCHKC(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (marg) HIPCHKC(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + GEN_BLOCK - 1) / GEN_BLOCK);
         switch (K) {
         case 2: launch_updown<2>(h, a, grid, deriv, marg); break;

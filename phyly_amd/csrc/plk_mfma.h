@@ -46,6 +46,47 @@ struct MfmaArgs {
     dd *partial;
 };
 
+/* pattern codes of the block's 64 sites for every observed node: 16 dwords per row; eight (node lookup, code dword)
+ * pairs per lane are in flight at a time instead of one */
+__device__ static inline void mf_stage_codes(uint8_t *code_lds, const uint8_t *codes, const int *obs_nodes, int nobs, long Spad,
+                                             size_t site0, int tid)
+{
+    uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
+    const int ndw = nobs * (MF_SITES / 4);
+    for (int i0 = tid; i0 < ndw; i0 += 8 * MF_BLOCK) {
+        int node[8];
+        uint32_t q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = i0 + u * MF_BLOCK; node[u] = idx < ndw ? obs_nodes[idx / (MF_SITES / 4)] : 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = i0 + u * MF_BLOCK, col = idx % (MF_SITES / 4);
+            q[u] = idx < ndw ? reinterpret_cast<const uint32_t *>(codes + (size_t)node[u] * Spad + site0)[col] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = i0 + u * MF_BLOCK; if (idx < ndw) dst[idx] = q[u]; }
+    }
+}
+
+/* A fragments of one matrix, L2 -> LDS, by the whole workgroup.  Eight 16-byte loads per lane are in flight before the
+ * first one is stored: as a plain copy loop the compiler emitted load, wait, store per iteration -- eight serialised L2
+ * round trips per staged matrix at k = 61, longer than the 64 matrix-core instructions that consume it. */
+__device__ static inline void mf_stage(double *lds_frag, const double *src, int nfrag, int tid)
+{
+    __syncthreads();
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(lds_frag);
+    const int n2 = nfrag / 2;
+    for (int i0 = tid; i0 < n2; i0 += 8 * MF_BLOCK) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = i0 + u * MF_BLOCK < n2 ? s2[i0 + u * MF_BLOCK] : double2{0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (i0 + u * MF_BLOCK < n2) d2[i0 + u * MF_BLOCK] = v[u];
+    }
+    __syncthreads();
+}
+
 template <int T>
 __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
 {
@@ -61,14 +102,7 @@ __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
 
     /* stage the code rows of this block's 64 sites (rows are padded to Spad, a multiple of 1024) */
     uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_frag + nfrag);
-    {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
-        for (int idx = tid; idx < a.nobs * (MF_SITES / 4); idx += MF_BLOCK) {
-            const int row = idx / (MF_SITES / 4), col = idx - row * (MF_SITES / 4);
-            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)a.obs_nodes[row] * a.Spad +
-                                                          (size_t)blockIdx.x * MF_SITES)[col];
-        }
-    }
+    mf_stage_codes(code_lds, a.codes, a.obs_nodes, a.nobs, a.Spad, (size_t)blockIdx.x * MF_SITES, tid);
     __syncthreads();
     const int scol = wave * 16 + (lane & 15);
 
@@ -90,11 +124,7 @@ __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
             const int code = op.x & 0xff;
             if (code == OP_MATVEC) {
                 /* stage the A fragments of this edge (same for all 4 waves) */
-                __syncthreads();
-                const double *src = a.frag + ((size_t)c * a.nops + pc) * nfrag;
-                for (int i = tid; i < nfrag / 2; i += MF_BLOCK)
-                    reinterpret_cast<double2 *>(lds_frag)[i] = reinterpret_cast<const double2 *>(src)[i];
-                __syncthreads();
+                mf_stage(lds_frag, a.frag + ((size_t)c * a.nops + pc) * nfrag, nfrag, tid);
                 plk_d4 acc[T];
 #pragma unroll
                 for (int t = 0; t < T; t++) acc[t] = (plk_d4){0.0, 0.0, 0.0, 0.0};

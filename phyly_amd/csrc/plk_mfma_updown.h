@@ -98,14 +98,6 @@ __device__ static inline void mf_matvec(const double *lds_frag, int kk4, int lan
     }
 }
 
-__device__ static inline void mf_stage(double *lds_frag, const double *src, int nfrag, int tid)
-{
-    __syncthreads();
-    for (int i = tid; i < nfrag / 2; i += MF_BLOCK)
-        reinterpret_cast<double2 *>(lds_frag)[i] = reinterpret_cast<const double2 *>(src)[i];
-    __syncthreads();
-}
-
 template <int T>
 __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_down_store_mfma(MUpArgs a)
 {
@@ -227,14 +219,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int NT = a.ntips + 1;
     const size_t n = (size_t)a.n;
     uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_frag + nfrag);
-    {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
-        for (int idx = tid; idx < pg.nobs * (MF_SITES / 4); idx += MF_BLOCK) {
-            const int row = idx / (MF_SITES / 4), col = idx - row * (MF_SITES / 4);
-            dst[idx] = reinterpret_cast<const uint32_t *>(a.codes + (size_t)pg.obs_nodes[row] * a.Spad + a.s0 +
-                                                          (size_t)blockIdx.x * MF_SITES)[col];
-        }
-    }
+    mf_stage_codes(code_lds, a.codes, pg.obs_nodes, pg.nobs, a.Spad, (size_t)a.s0 + (size_t)blockIdx.x * MF_SITES, tid);
     __syncthreads();
     const int scol = wave * 16 + (lane & 15);
     const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(pg.ops));

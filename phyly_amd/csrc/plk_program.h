@@ -427,9 +427,13 @@ static inline std::string plk_fused_check_cpp(int N, const PlkProgram &pg, const
 struct PlkChain {
     std::vector<plk_op4> ops;          /* + one trailing OP_END (k_down_fused4 reads one op ahead) */
     int first_slot = -1, first_row = 0;
+    int second_row = 0;                /* mode 3: staged row of the second observation op */
 };
 
-/* mode 0: MATVEC keeps (x, y) of the program (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
+/* mode 3 (k_ll_vec, k_down_vec): as mode 1, and every observation op also carries in y the staged row of the observation
+ * op AFTER the next one (the prefetch chain runs two ops ahead: value of the next op, code of the one after; the
+ * sequence wraps to the start for the next category); MATVEC w = CSR edge of the next MATVEC.
+ * mode 0: MATVEC keeps (x, y) of the program (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
  * child node, w = CSR edge of the next MATVEC, wrapping to the first (k_down_fused4, k_down_vec); mode 2: as 1 but
  * w = storage index of the edge (k_down_fused_mfma, no chain).  SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
 static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const int *indices, const int *node_int,
@@ -454,23 +458,35 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
             }
         } else if (code == OP_MATVEC && mode >= 1) {
             o.y = pg.op_edge[pc];
-            o.z = node_int[indices[o.y]];
+            o.z = node_int ? node_int[indices[o.y]] : 0;
             if (mode == 2) o.w = edge_int[o.y];
-        } else if (code == OP_SCALE && mode >= 1) {
+        } else if (code == OP_SCALE && mode >= 1 && node_scale) {
             o.y = node_scale[pg.ops[pc].y];
         }
         ch.ops[pc] = o;
     }
     if (prev >= 0) { ch.ops[prev].z = ch.first_slot | (1 << 30); ch.ops[prev].w = ch.first_row; }
-    if (mode == 1) {
+    if (mode == 3) {
+        /* y of an observation op = staged row of the op two observations later (cyclically) */
+        std::vector<int> opc_, rows_;
+        for (size_t pc = 0; pc < pg.ops.size(); pc++) {
+            const int code = pg.ops[pc].x & 0xff;
+            if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) { opc_.push_back((int)pc); rows_.push_back(ch.ops[pc].y); }
+        }
+        const size_t no = opc_.size();
+        ch.second_row = no ? rows_[1 % no] : 0;
+        for (size_t i = 0; i < no; i++) ch.ops[opc_[i]].y = rows_[(i + 2) % no];
+    }
+    if (mode == 1 || mode == 3) {
+        /* MATVEC w = CSR edge of the next MATVEC (wrapping); without node storage (ll kernels) z = its op index */
         int first_mv = -1, prev_mv = -1;
         for (size_t pc = 0; pc < pg.ops.size(); pc++)
             if ((pg.ops[pc].x & 0xff) == OP_MATVEC) {
                 if (first_mv < 0) first_mv = (int)pc;
-                if (prev_mv >= 0) ch.ops[prev_mv].w = pg.op_edge[pc];
+                if (prev_mv >= 0) { ch.ops[prev_mv].w = pg.op_edge[pc]; if (!node_int) ch.ops[prev_mv].z = (int)pc; }
                 prev_mv = (int)pc;
             }
-        if (prev_mv >= 0) ch.ops[prev_mv].w = pg.op_edge[first_mv];
+        if (prev_mv >= 0) { ch.ops[prev_mv].w = pg.op_edge[first_mv]; if (!node_int) ch.ops[prev_mv].z = first_mv; }
     }
 }
 
@@ -635,6 +651,10 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
         const int code = o.x & 0xff;
         if (code != (pg.ops[pc].x & 0xff)) return "down program: opcode mismatch";
         if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+            if (mode == 3) {
+                /* two-ahead chain: y = row of the observation after next (cyclic) */
+                if (o.y < 0 || o.y >= nobs || o.y != rowv[(oi + 2) % rowv.size()]) return plk_fmt("down program: op %ld prefetches the wrong row", pc);
+            } else
             if (o.y < 0 || o.y >= nobs || o.y != rowv[oi]) return plk_fmt("down program: op %ld names the wrong staged row", pc);
             if (code != OP_NODE_MUL && ((o.x >> 8) < 0 || (o.x >> 8) >= ntips)) return "down program: tip slot out of range";
             if (mode != 2) {
@@ -647,15 +667,16 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
             }
             oi++;
         } else if (code == OP_MATVEC && mode >= 1) {
-            if (o.y != pg.op_edge[pc] || o.z < 0 || o.z >= nint_nodes) return plk_fmt("down program: op %ld stores to a bad node index", pc);
+            if (o.y != pg.op_edge[pc] || o.z < 0 || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
             if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
         } else if (code == OP_PUSH || code == OP_POPMUL) {
             if (o.y < 0 || o.y >= D) return "down program: stack slot out of range";
-        } else if (code == OP_SCALE && mode >= 1) {
+        } else if (code == OP_SCALE && mode >= 1 && nscale_slots > 0) {
             if (o.y < -1 || o.y >= nscale_slots) return "down program: rescaling slot out of range";
         }
     }
     if (oi != slot.size()) return "down program: observation count";
+    if (mode == 3 && !rowv.empty() && ch.second_row != rowv[1 % rowv.size()]) return "down program: second row";
     return "";
 }
 

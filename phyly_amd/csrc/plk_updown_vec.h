@@ -33,9 +33,12 @@ struct UpVecArgs {
     int N, E, k, C, nchar, ntips, root_mode;
     int dzero;                     /* 1: edge-form matrices have zero row sums (dP) */
     /* down pass: program (int4: observation y = node; MATVEC y = CSR edge, z = storage index of the child node,
-     * w = CSR edge of the next MATVEC (wrapping); PUSH / POPMUL y = slot; SCALE y = rescaling slot or -1) */
+     * w = CSR edge of the next MATVEC (wrapping); PUSH / POPMUL y = slot; SCALE y = rescaling slot or -1);
+     * plk_chain_build mode 3: observation ops y = staged row of the observation after next, z = tip slot of the next one
+     * (bit 30: next category), w = its row */
     const int4 *ops;
     int nops, root_int;
+    int first_slot, first_row, second_row;
     const double *PT;              /* [C][E][K*K] transposed P: PT[j*K+i] = P[i][j] (down pass) */
     const double *tip, *dtip;      /* [C][ntips+1][nchar][K]: P_e defs (slot ntips: defs themselves); M_e defs */
     const uint8_t *codes;
@@ -112,6 +115,17 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
     const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
     int xmax = INT_MIN;
+    /* observation prefetch chain, two ops deep (see k_ll_vec) */
+    double nv[K];
+    int code_next = 0;
+    if (a.first_slot >= 0) {
+        const int ch0 = a.codes[(size_t)obs[a.first_row] * a.Spad + sg];
+        udv_gather<K>(a.tip + ((size_t)a.first_slot * a.nchar + ch0) * K, nv);
+        code_next = a.codes[(size_t)obs[a.second_row] * a.Spad + sg];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; i++) nv[i] = 1.0;
+    }
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -134,17 +148,18 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = cst ? (i < a.k ? x0 : 0.0) : acc[i];   /* src/util.c:276-283 */
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
-                const int ch = a.codes[(size_t)obs[oy] * a.Spad + sg];
-                double v[K];
-                udv_gather<K>(tipc + ((size_t)t * a.nchar + ch) * K, v);
+                const int oz = ops[4 * pc + 2];
                 if (code == OP_TIP_SET) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) cur[i] = v[i];
+                    for (int i = 0; i < K; i++) cur[i] = nv[i];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < K; i++) cur[i] *= v[i];
+                    for (int i = 0; i < K; i++) cur[i] *= nv[i];
                 }
+                const int wrap = (oz >> 30) & 1;
+                if (!wrap || c + 1 < a.C)
+                    udv_gather<K>(tipc + (size_t)wrap * tabc + ((size_t)(oz & 0x3fffffff) * a.nchar + code_next) * K, nv);
+                code_next = a.codes[(size_t)obs[oy] * a.Spad + sg];
             } else if (code == OP_PUSH) {
                 if (valid) udv_store<K>(a.slots + (size_t)oy * K * n, n, slc, cur);
             } else if (code == OP_POPMUL) {

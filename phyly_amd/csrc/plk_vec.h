@@ -20,7 +20,11 @@
 struct VecArgs {
     long S, Spad;
     int k, C, nops, ntips, nchar, root_mode;
-    const int2 *ops;          /* x = opcode | tip<<8, y = node / slot; OP_MATVEC: y = pc of the next OP_MATVEC (wrapping) */
+    const int4 *ops;          /* plk_chain_build mode 3 without node storage: observation ops y = staged row of the observation
+                                 after next, z = tip slot of the next one (bit 30: it belongs to the next category), w = its
+                                 row; MATVEC z = op index of the next MATVEC (wrapping); PUSH / POPMUL y = slot */
+    const int *obs_nodes;     /* node of every staged row */
+    int first_slot, first_row, second_row;
     const double *PS;         /* [C][nops][K*K]: PS[j*K + i] = P[i][j], zero padded */
     const double *tip;        /* [C][ntips+1][nchar][K]: P_e defs[code]; last slot = the definitions themselves */
     const uint8_t *codes;     /* [N][Spad] */
@@ -79,6 +83,23 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
+    /* Observation prefetch chain, two ops deep: while an observation op multiplies its tip-table row into the vector,
+     * the row of the NEXT observation op is already being gathered (its pattern code arrived during the previous op)
+     * and the code of the one after that is being loaded.  Without it every observation op waits for two dependent
+     * global loads (code, then table row): 200 of them per site at BASELINE config 4, more than the 198 products. */
+    const PLK_AS4 int *obs = as_uniform(a.obs_nodes);
+    double nv[K];
+    int code_next = 0;
+    if (a.first_slot >= 0) {
+        const int ch0 = a.codes[(size_t)obs[a.first_row] * a.Spad + sc];
+        const double2 *tp = reinterpret_cast<const double2 *>(a.tip + ((size_t)a.first_slot * a.nchar + ch0) * K);
+#pragma unroll
+        for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; nv[i] = v.x; nv[i + 1] = v.y; }
+        code_next = a.codes[(size_t)obs[a.second_row] * a.Spad + sc];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; i++) nv[i] = 1.0;
+    }
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -87,29 +108,38 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
         const PLK_AS4 double *PSc = as_uniform(a.PS) + (size_t)c * a.nops * K * K;
         const double *tipc = a.tip + (size_t)c * tabc;
         for (int pc = 0; pc < a.nops; pc++) {
-            const int ox = ops[2 * pc], oy = ops[2 * pc + 1];
+            const int ox = ops[4 * pc], oy = ops[4 * pc + 1];
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
+                const int oz = ops[4 * pc + 2];
                 const PLK_AS4 double *M = PSc + (size_t)pc * K * K;
                 /* request (and wait for) the lines of the NEXT product's matrix -- the next category's first one at
                  * the end -- before multiplying with this one, whose lines the previous product requested */
-                const int nc = oy <= pc ? c + 1 : c;
-                vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oy) * K * K);
+                const int nc = oz <= pc ? c + 1 : c;
+                vec_touch<K>(as_uniform(a.PS) + ((size_t)(nc < a.C ? nc : c) * a.nops + oz) * K * K);
                 double acc[K];
                 vec_matvec<K>(M, cur, acc);
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = acc[i];
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
-                const int ch = a.codes[(size_t)oy * a.Spad + sc];
-                const double2 *tp = reinterpret_cast<const double2 *>(tipc + ((size_t)t * a.nchar + ch) * K);
+                const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
+                (void)ow;
                 if (code == OP_TIP_SET) {
 #pragma unroll
-                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] = v.x; cur[i + 1] = v.y; }
+                    for (int i = 0; i < K; i++) cur[i] = nv[i];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] *= v.x; cur[i + 1] *= v.y; }
+                    for (int i = 0; i < K; i++) cur[i] *= nv[i];
                 }
+                /* next observation: its code is here, gather its row; then ask for the code of the one after */
+                const int wrap = (oz >> 30) & 1;
+                if (!wrap || c + 1 < a.C) {
+                    const double2 *tp = reinterpret_cast<const double2 *>(tipc + (size_t)wrap * tabc +
+                                                                          ((size_t)(oz & 0x3fffffff) * a.nchar + code_next) * K);
+#pragma unroll
+                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; nv[i] = v.x; nv[i + 1] = v.y; }
+                }
+                code_next = a.codes[(size_t)obs[oy] * a.Spad + sc];
             } else if (code == OP_PUSH) {
                 double *sp = a.slots + (size_t)oy * K * a.S + sc;
                 if (valid) {

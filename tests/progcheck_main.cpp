@@ -57,8 +57,14 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
     for (int e = 0; e < E; e++) if (edge_tip[e] < 0) edge_int[e] = nie++;
     for (int a = 0; a < N; a++) if (t.ip[a + 1] > t.ip[a]) node_int[a] = nin++;
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && pg.scale_node[a]) node_scale[a] = nsc++;
-    for (int mode = 0; mode <= 2; mode++) {
+    for (int mode = 0; mode <= 4; mode++) {
         PlkChain ch;
+        if (mode == 4) {          /* mode 3 without node storage (the vector ll kernel) */
+            plk_chain_build(N, pg, 3, t.ix.data(), nullptr, nullptr, nullptr, ch);
+            bad = plk_chain_check(N, pg, ch, 3, 1 << 30, 0, 0, 0, 0, 0);
+            if (!bad.empty()) return "mode 3 (ll): " + bad;
+            continue;
+        }
         plk_chain_build(N, pg, mode, t.ix.data(), node_int.data(), edge_int.data(), node_scale.data(), ch);
         const int block = mode == 1 ? 256 : 64;
         bad = plk_chain_check(N, pg, ch, mode, 1 << 30, nin, nie, nsc, block, pg.obs_nodes.size() * (size_t)block);

@@ -349,3 +349,14 @@ def test_character_data_file_side_channel(validate, tmp_path):
     bad = copy.deepcopy(x)
     bad["model_and_data"]["character_data_file"] = 17
     assert validate(bad) != 0
+
+
+def test_single_node_tree_is_rejected_with_a_diagnostic(validate, capfd):
+    """Documented deviation (DESIGN.md): `edges: []` is a one-node tree in the reference (parsemodel.c:230-231);
+    the engine requires an edge, and the host layer rejects the model up front instead of failing inside plk_set_tree."""
+    x = {"model_and_data": {"edges": [], "edge_rate_coefficients": [],
+                            "rate_matrix": [[0, 1.0], [1.0, 0]],
+                            "probability_array": [[[1, 0]]]},
+         "site_reduction": {"aggregation": "sum"}}
+    assert validate(x) != 0
+    assert "single node" in capfd.readouterr().err
