@@ -205,7 +205,7 @@ enum {
     PLK_INFO_LAST_LL_TOTAL_NS = 4,  /* HIP-event time of the last whole plk_ll device work */
     PLK_INFO_LL_KERNEL_NS_SUM = 5,  /* HIP-event time of the traversal kernels of all ll evaluations since this item was */
     PLK_INFO_LL_KERNEL_COUNT = 6,   /* last read, and their number (reading waits for queued evaluations, then resets) */
-    PLK_INFO_LL_VARIANT = 7         /* fused k = 4 kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter */
+    PLK_INFO_LL_VARIANT = 7         /* k = 4 tile kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter, 0 another kernel */
 };
 
 /* force the generic (HBM-resident partials) traversal even where the fused

@@ -1408,12 +1408,20 @@ static size_t mfma_ll_lds_bytes(const plk_engine *h)
     return (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)64;
 }
 
+/* k = 4 tile kernels: the assembly interpreter stages 4-bit codes when there are at most 16 character definitions,
+ * which lets it take about twice the taxa of the C++ interpreter before the tile no longer fits the LDS */
+static bool fused_asm_fits(const plk_engine *h)
+{
+    if (fused_sites_per_lane(h) != 1 || !plk_fused_asm_ok(h->pg) || !h->opt_fused_asm) return false;
+    return plk_fused_lds_bytes(h->pg, h->nchar, h->nchar <= 16 ? PLK_TILE / 2 : PLK_TILE) <= PLK_LDS_LIMIT;
+}
+
 static bool use_fused(const plk_engine *h)
 {
     if (h->opt_force_generic) return false;
     if (h->k != 4 || h->pat_mode != 1) return false;
     if (h->slots_needed > PLK_FUSED_SLOTS) return false;
-    return plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * fused_sites_per_lane(h)) <= PLK_LDS_LIMIT;
+    return fused_asm_fits(h) || plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * fused_sites_per_lane(h)) <= PLK_LDS_LIMIT;
 }
 
 /* Device formats of the program for kernel kind (1 fused k = 4, 2 generic, 3 matrix cores, 4 vector): uploaded when
@@ -1562,6 +1570,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
     h->evk_next = (evi + 1) & 63;
     if ((rc = evk_resolve(h, evi))) return rc;           /* only waits when 64 evaluations are queued */
     HIPCHK(h, hipEventRecord(h->evk[evi][0], h->stream));
+    h->info_ll_variant = 0;
     if (fused) {
         const int NS = fused_sites_per_lane(h);
         grid = (unsigned)((S + PLK_TILE * NS - 1) / (PLK_TILE * NS));
@@ -1575,7 +1584,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.site_ll = d_out; a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         a.root_mode = h->root_mode; a.first_row = h->fu.first_row;
         const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
-        const bool use_asm = NS == 1 && h->fu.asm_ok && h->opt_fused_asm;
+        const bool use_asm = fused_asm_fits(h);
         const int D = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : 16);
         if (use_asm) {
             FusedAsmArgs aa;

@@ -215,6 +215,12 @@ struct PlkFused {
     bool asm_ok = false;               /* the assembly interpreter's field widths and stack depth suffice */
 };
 
+/* the assembly interpreter's op-word fields: 8 stack slots, 13 bits of tip slot, 16 bits of staged row */
+static inline bool plk_fused_asm_ok(const PlkProgram &pg)
+{
+    return pg.slots_needed <= 8 && pg.tip_edge.size() + 1 < 8192 && pg.obs_nodes.size() < 65536;
+}
+
 static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
 {
     const int nops = (int)pg.ops.size();
@@ -269,7 +275,7 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
     fu.asm_first_tip = obs_t.empty() ? 0 : obs_t[0];
     fu.asm_first_row = obs_row.empty() ? 0 : obs_row[0];
     fu.asm_second_row = obs_row.size() > 1 ? obs_row[1] : 0;
-    fu.asm_ok = pg.slots_needed <= 8 && ntips + 1 < 8192 && pg.obs_nodes.size() < 65536;
+    fu.asm_ok = plk_fused_asm_ok(pg);
 }
 
 /* dynamic LDS of the fused ll kernels: tip tables of ncat categories (ntips + the pseudo slot each) + staged code rows */

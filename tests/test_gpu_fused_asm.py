@@ -74,13 +74,17 @@ def test_wide_codes_and_node_data(eng, oracle):
         assert np.max(np.abs(out[variant][0] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12
 
 
-def test_deep_tree_rescaling(eng, oracle):
-    wl = synth.Workload(T=700, k=4, tree="yule", model="gtr_g4", seed=9)
+@pytest.mark.parametrize("T,variant", [(430, 1), (700, 0)])
+def test_deep_tree_rescaling(eng, oracle, T, variant):
+    """430 taxa: the largest tip tables the assembly interpreter's LDS budget takes (rescaling ops every few levels);
+    700 taxa: beyond it (variant 0: the general kernel takes over), and site likelihoods fall below the smallest double"""
+    wl = synth.Workload(T=T, k=4, tree="yule", model="gtr_g4", seed=9)
     wl.setup_engine(eng)
     codes = wl.simulate(300)
     eng.set_patterns_codes(codes, wl.defs)
     ll, _ = eng.ll()
-    assert eng.info(E.INFO_LL_VARIANT) == 1
+    assert eng.info(E.INFO_LL_VARIANT) == variant
     want = oracle_site_ll(oracle, wl, codes)
-    assert np.min(want) < -745
+    if T == 700:
+        assert np.min(want) < -745
     assert np.max(np.abs(ll - want) / np.abs(want)) <= 1e-12
