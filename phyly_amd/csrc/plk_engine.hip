@@ -127,7 +127,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
@@ -1097,6 +1097,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_SITE_CHUNK) { h->opt_site_chunk = value; return PLK_OK; }
     if (option == PLK_OPT_FUSED_SITES_PER_LANE) { h->opt_fused_ns = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
+    if (option == PLK_OPT_UP_NODES) { h->opt_up_nodes = value; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
@@ -2099,10 +2100,11 @@ static bool use_updown_vec(const plk_engine *h)
 }
 
 template <int K>
-static void launch_updown_vec(plk_engine *h, const UpVecArgs &a, const int *d_obs, unsigned grid, bool deriv, bool marg)
+static void launch_updown_vec(plk_engine *h, const UpVecArgs &a, const int *d_obs, unsigned grid, bool deriv, bool marg, bool nodes)
 {
     hipLaunchKernelGGL(k_down_vec<K>, dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a, d_obs);
-    if (deriv && marg) hipLaunchKernelGGL((k_up_vec<K, true, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+    if (nodes) hipLaunchKernelGGL(k_up_nodes<K>, dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+    else if (deriv && marg) hipLaunchKernelGGL((k_up_vec<K, true, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
     else if (deriv) hipLaunchKernelGGL((k_up_vec<K, true, false>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
     else hipLaunchKernelGGL((k_up_vec<K, false, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
 }
@@ -2124,12 +2126,23 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
     PlkChain ch;
     plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
+    /* derivative queries without marginals take the node-visit up pass (k_up_nodes); PLK_OPT_UP_NODES = 0 keeps the
+     * one-edge-at-a-time kernel for them too */
+    const bool nodes = deriv && !marg && h->opt_up_nodes;
     PlkUpVisits uv;
-    plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                        node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
     {
         std::string bad = plk_chain_check(N, h->pg, ch, 3, INT_MAX, nin, nie, nsc, 0, 0);
-        if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
+        if (nodes) {
+            PlkUpNodes un;
+            plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                               node_int.data(), node_scale.data(), edge_mask, un);
+            if (bad.empty()) bad = plk_up_nodes_check(N, E, un, nin, ntips, nsc);
+            uv.rec.swap(un.rec); uv.kind.swap(un.kind); uv.edge.swap(un.edge); uv.nvisits = un.nvisits;
+        } else {
+            plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                                node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
+            if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
+        }
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
     const int nstream = (int)uv.kind.size();
@@ -2198,8 +2211,8 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UDV_BLOCK - 1) / UDV_BLOCK);
-        if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg);
-        else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg);
+        if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg, nodes);
+        else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg, nodes);
         if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;

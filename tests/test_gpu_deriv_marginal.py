@@ -171,3 +171,36 @@ def test_deep_tree_rescaling_generic_and_mfma(eng, oracle):
     assert _row_err(got, oracle.site_deriv(m, ow, B, precise=2)) <= 1e-12
     gotm, _ = eng.marginal()
     assert np.max(np.abs(gotm - oracle.site_marginal(m, ow, B, precise=2))) <= 1e-12
+
+
+@pytest.mark.parametrize("cfg_or_k", [4])
+def test_node_visit_up_pass_equals_edge_up_pass(eng, oracle, cfg_or_k):
+    """9 <= k <= 20, derivative queries: k_up_nodes (default) against the one-edge-at-a-time k_up_vec
+    (PLK_OPT_UP_NODES = 0) and the oracle, all edges and a sparse edge mask, several site chunks (K = 16 and trees with
+    multifurcations, unary nodes and data at internal nodes: test_gpu_differential.py::test_medium_and_large_state_spaces)"""
+    from phyly_amd import synth, engine as E
+    w = synth.Workload(cfg_or_k)
+    w.setup_engine(eng)
+    S = 300
+    codes = w.simulate(S)
+    eng.set_patterns_codes(codes, w.defs)
+    eng.set_site_weights(None)
+    mask = np.zeros(w.E, dtype=np.int32)
+    mask[[1, 7, w.E // 2, w.E - 1]] = 1
+    out = {}
+    for nodes in (1, 0):
+        eng.set_option(E.OPT_UP_NODES, nodes)
+        eng.set_option(E.OPT_SITE_CHUNK, 128)
+        out[nodes] = (eng.deriv()[0], eng.deriv(edge_mask=mask)[0])
+    eng.set_option(E.OPT_UP_NODES, 1)
+    eng.set_option(E.OPT_SITE_CHUNK, 0)
+    for q in (0, 1):
+        scale = np.max(np.abs(out[0][q]), axis=1, keepdims=True)
+        assert np.max(np.abs(out[1][q] - out[0][q]) / np.maximum(scale, 1e-300)) <= 1e-13
+    sel = mask.astype(bool)
+    assert np.all(out[1][1][:, ~sel] == 0.0)
+    assert np.max(np.abs(out[1][1][:, sel] - out[1][0][:, sel])) == 0.0
+    if cfg_or_k == 4:
+        m, ow = oracle_model(oracle, w, codes[:, :40])
+        want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes[:, :40]), precise=1)
+        assert _row_err(out[1][0][:40], want) <= 1e-12

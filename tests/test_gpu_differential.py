@@ -220,3 +220,6 @@ def test_medium_and_large_state_spaces(oracle, k):
         if any(not np.isfinite(r[-1]) for r in want["data"]):
             pytest.skip("zero-likelihood site drawn")
         _check(kind, json.loads(prod(s)), want)
+    # a derivative query for a few edges only (edge mask: the node-visit up pass prunes the visits below)
+    s = json.dumps({"model_and_data": md, "edge_reduction": {"selection": [0, 3, 3, n_nodes - 2]}})
+    _check("deriv", json.loads(arbplf.arbplf_deriv(s)), json.loads(oracle.arbplf_deriv(s)))
