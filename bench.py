@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the config's S)")
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
     ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="ID=VALUE",
+                    help="plk_set_option(ID, VALUE) before the run (kernel experiments; include/plk.h lists the options)")
     ap.add_argument("--categories", type=int, default=0, help="override the number of Gamma categories (experiments; not the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
@@ -117,6 +119,9 @@ def main():
         eng.set_option(E.OPT_FORCE_GENERIC, 1)
     if args.fused_ns:
         eng.set_option(E.OPT_FUSED_NS, args.fused_ns)
+    for kv in args.engine_option:
+        oid, val = kv.split("=")
+        eng.set_option(int(oid), int(val))
 
     # resident patterns: this rank's block of the alignment, generated on the GPU
     chunk = 1 << 20

@@ -215,8 +215,9 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
        PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */,
        PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
                            33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */,
-       PLK_OPT_UP_NODES = 5 /* 1 (default): derivative queries of 9 <= k <= 20 use the node-visit up pass (one read of every
-                               stored vector); 0: the one-edge-at-a-time up pass that marginal queries use */ };
+       PLK_OPT_UP_NODES = 5 /* 1: derivative queries of 9 <= k <= 20 use the node-visit up pass (one read of every stored
+                               vector, two waves per SIMD: measured slower, kept for the next round's work);
+                               0 (default): the one-edge-at-a-time up pass that marginal queries use too */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

@@ -127,7 +127,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 1;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 0;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
@@ -1040,6 +1040,9 @@ extern "C" int plk_create(plk_engine **out, int device)
     }
     plk_engine *h = new plk_engine();
     h->device = device;
+    /* ARBPLF_UP_NODES = 1: initial value of PLK_OPT_UP_NODES, so that the JSON drivers (which own their engines) can be
+     * run with the node-visit up pass: tests/test_gpu_differential.py does */
+    if (const char *v = getenv("ARBPLF_UP_NODES")) h->opt_up_nodes = atol(v);
     if (hipStreamCreate(&h->own_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreate(&h->ev2) != hipSuccess || hipEventCreate(&h->ev3) != hipSuccess) {
@@ -2126,8 +2129,9 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
     PlkChain ch;
     plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
-    /* derivative queries without marginals take the node-visit up pass (k_up_nodes); PLK_OPT_UP_NODES = 0 keeps the
-     * one-edge-at-a-time kernel for them too */
+    /* PLK_OPT_UP_NODES = 1: derivative queries without marginals take the node-visit up pass (k_up_nodes: a third of
+     * the HBM reads, but two waves per SIMD -- 60 ms against 28 ms per million sites at BASELINE config 4, so not the
+     * default) */
     const bool nodes = deriv && !marg && h->opt_up_nodes;
     PlkUpVisits uv;
     {

@@ -175,8 +175,8 @@ def test_deep_tree_rescaling_generic_and_mfma(eng, oracle):
 
 @pytest.mark.parametrize("cfg_or_k", [4])
 def test_node_visit_up_pass_equals_edge_up_pass(eng, oracle, cfg_or_k):
-    """9 <= k <= 20, derivative queries: k_up_nodes (default) against the one-edge-at-a-time k_up_vec
-    (PLK_OPT_UP_NODES = 0) and the oracle, all edges and a sparse edge mask, several site chunks (K = 16 and trees with
+    """9 <= k <= 20, derivative queries: k_up_nodes (PLK_OPT_UP_NODES = 1) against the one-edge-at-a-time k_up_vec
+    (the default) and the oracle, all edges and a sparse edge mask, several site chunks (K = 16 and trees with
     multifurcations, unary nodes and data at internal nodes: test_gpu_differential.py::test_medium_and_large_state_spaces)"""
     from phyly_amd import synth, engine as E
     w = synth.Workload(cfg_or_k)
@@ -192,7 +192,7 @@ def test_node_visit_up_pass_equals_edge_up_pass(eng, oracle, cfg_or_k):
         eng.set_option(E.OPT_UP_NODES, nodes)
         eng.set_option(E.OPT_SITE_CHUNK, 128)
         out[nodes] = (eng.deriv()[0], eng.deriv(edge_mask=mask)[0])
-    eng.set_option(E.OPT_UP_NODES, 1)
+    eng.set_option(E.OPT_UP_NODES, 0)
     eng.set_option(E.OPT_SITE_CHUNK, 0)
     for q in (0, 1):
         scale = np.max(np.abs(out[0][q]), axis=1, keepdims=True)

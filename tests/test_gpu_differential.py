@@ -220,6 +220,17 @@ def test_medium_and_large_state_spaces(oracle, k):
         if any(not np.isfinite(r[-1]) for r in want["data"]):
             pytest.skip("zero-likelihood site drawn")
         _check(kind, json.loads(prod(s)), want)
-    # a derivative query for a few edges only (edge mask: the node-visit up pass prunes the visits below)
-    s = json.dumps({"model_and_data": md, "edge_reduction": {"selection": [0, 3, 3, n_nodes - 2]}})
-    _check("deriv", json.loads(arbplf.arbplf_deriv(s)), json.loads(oracle.arbplf_deriv(s)))
+    # a derivative query for a few edges only (edge mask)
+    full = json.dumps({"model_and_data": md})
+    few = json.dumps({"model_and_data": md, "edge_reduction": {"selection": [0, 3, 3, n_nodes - 2]}})
+    _check("deriv", json.loads(arbplf.arbplf_deriv(few)), json.loads(oracle.arbplf_deriv(few)))
+    if k <= 20:
+        # the same two queries through the arbplf-deriv executable with the node-visit up pass (k_up_nodes, opt-in):
+        # random trees here have multifurcations, unary nodes and data at internal nodes, and two rate categories
+        import os
+        import subprocess
+        exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phyly_amd", "csrc", "arbplf-deriv")
+        for q in (full, few):
+            r = subprocess.run([exe], input=q, capture_output=True, text=True, timeout=300, env=dict(os.environ, ARBPLF_UP_NODES="1"))
+            assert r.returncode == 0, r.stderr
+            _check("deriv", json.loads(r.stdout), json.loads(oracle.arbplf_deriv(q)))
