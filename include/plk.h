@@ -215,9 +215,10 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
        PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */,
        PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
                            33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */,
-       PLK_OPT_UP_NODES = 5 /* 1: derivative queries of 9 <= k <= 20 use the node-visit up pass (one read of every stored
-                               vector, two waves per SIMD: measured slower, kept for the next round's work);
-                               0 (default): the one-edge-at-a-time up pass that marginal queries use too */ };
+       PLK_OPT_UP_NODES = 5 /* 1: derivative queries on the matrix-core kernels (21 <= k <= 64, or all of 9 <= k <= 64 under
+                               PLK_OPT_MFMA = 2) use the node-visit up pass over stored edge vectors (fewer HBM bytes, same
+                               speed as measured in round 2); 0 (default): the one-edge-at-a-time up pass that marginal
+                               queries use too.  ARBPLF_UP_NODES in the environment sets the initial value. */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

@@ -1041,7 +1041,7 @@ extern "C" int plk_create(plk_engine **out, int device)
     plk_engine *h = new plk_engine();
     h->device = device;
     /* ARBPLF_UP_NODES = 1: initial value of PLK_OPT_UP_NODES, so that the JSON drivers (which own their engines) can be
-     * run with the node-visit up pass: tests/test_gpu_differential.py does */
+     * run with the node-visit up pass too: tests/test_gpu_differential.py compares the two */
     if (const char *v = getenv("ARBPLF_UP_NODES")) h->opt_up_nodes = atol(v);
     if (hipStreamCreate(&h->own_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
@@ -1409,7 +1409,7 @@ static bool use_mfma(const plk_engine *h)
 static size_t mfma_ll_lds_bytes(const plk_engine *h)
 {
     const int T = (h->k + 15) / 16, kk4 = (h->k + 3) / 4;
-    return (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)64;
+    return (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)MF_SITES;
 }
 
 /* k = 4 tile kernels: the assembly interpreter stages 4-bit codes when there are at most 16 character definitions,
@@ -1796,14 +1796,17 @@ static int copy_site_rows(plk_engine *h, size_t rows, long n, long s0, const dou
 }
 
 template <int T>
-static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, const MDownProg &pg, unsigned grid, size_t lds, bool deriv, bool marg)
+static void launch_updown_mfma(plk_engine *h, const MUpArgs &a, const MDownProg &pg, unsigned grid, size_t lds, bool deriv, bool marg, bool nodes)
 {
     const size_t lds_down = lds + (size_t)pg.nobs * MF_SITES;
-    if (lds_down <= 60 * 1024 && (a.s0 % MF_SITES) == 0)
-        hipLaunchKernelGGL(k_down_fused_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds_down, h->stream, a, pg);
+    if (nodes)          /* the caller has checked that the depth-first down pass fits */
+        hipLaunchKernelGGL((k_down_fused_mfma<T, false>), dim3(grid), dim3(MF_BLOCK), lds_down, h->stream, a, pg);
+    else if (lds_down <= 60 * 1024 && (a.s0 % MF_SITES) == 0)
+        hipLaunchKernelGGL((k_down_fused_mfma<T, true>), dim3(grid), dim3(MF_BLOCK), lds_down, h->stream, a, pg);
     else
         hipLaunchKernelGGL(k_down_store_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
-    if (deriv && marg) hipLaunchKernelGGL((k_up_mfma<T, true, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    if (nodes) hipLaunchKernelGGL(k_up_nodes_mfma<T>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+    else if (deriv && marg) hipLaunchKernelGGL((k_up_mfma<T, true, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
     else if (deriv) hipLaunchKernelGGL((k_up_mfma<T, true, false>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
     else hipLaunchKernelGGL((k_up_mfma<T, false, true>), dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
 }
@@ -1842,6 +1845,19 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     const int nslots_m = std::max(h->slots_needed, 1);
     auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+    /* PLK_OPT_UP_NODES = 1: derivative queries without marginals take the node-visit up pass over edge vectors only
+     * (k_up_nodes_mfma), when the depth-first down pass applies (its staged code rows fit the LDS).  Measured equal to
+     * k_up_mfma at BASELINE config 5 (32.1 against 31.7 ms per step: the down pass gains what the up pass loses), so
+     * not the default; DESIGN.md section 4 has the counters */
+    const bool nodes = deriv && !marg && h->opt_up_nodes &&
+                       (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)MF_SITES <= 60 * 1024;
+    PlkUpNodes un;
+    if (nodes) {
+        plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                           node_int.data(), node_scale.data(), edge_mask, un);
+        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un, nin, ntips, nsc);
+        if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+    }
     /* the call's integer tables, one upload: [ops (16-byte aligned first)][edge_tip][edge_int][node_int][tip edges][node_scale]
      * [obs nodes][has_data][edge mask][node mask] */
     std::vector<int> pack;
@@ -1853,6 +1869,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     std::vector<int> hd(h->node_has_data.begin(), h->node_has_data.end());
     const size_t o_has = put(hd.data(), (size_t)N);
     const size_t o_em = edge_mask ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
+    const size_t o_vis = nodes ? put(un.rec.data(), un.rec.size()) : 0;
     const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
     if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4)) ||
         (rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, 2 * ntab + rwd.size())) ||
@@ -1868,7 +1885,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     double *d_tipd = h->d_u4tip, *d_dtip = d_tipd + ntab, *d_rwd = d_dtip + ntab;
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, h->d_P, d_fP);
     hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 1, h->d_P, d_fPT);
-    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, 0, d_M, d_fD);
+    hipLaunchKernelGGL(k_build_frag_edges, dim3(C * E), dim3(256), 0, h->stream, k, T, kk4, nodes ? 1 : 0, d_M, d_fD);   /* node visits apply M^T */
     hipLaunchKernelGGL(k_build_tip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
                        k, R, E, ntips, h->nchar, d_te, h->d_Pdd, h->d_defs, h->K, d_tipd);
     hipLaunchKernelGGL(k_build_dtip_dist, dim3(ntips + 1, C), dim3(256), 0, h->stream,
@@ -1916,10 +1933,12 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
-        if (T == 1) launch_updown_mfma<1>(h, a, pg, grid, lds, deriv, marg);
-        else if (T == 2) launch_updown_mfma<2>(h, a, pg, grid, lds, deriv, marg);
-        else if (T == 3) launch_updown_mfma<3>(h, a, pg, grid, lds, deriv, marg);
-        else launch_updown_mfma<4>(h, a, pg, grid, lds, deriv, marg);
+        a.visits = nodes ? pk + o_vis : nullptr; a.nvisits = un.nvisits;
+        const bool nv = nodes && (s0 % MF_SITES) == 0;       /* chunks start at multiples of the site tile */
+        if (T == 1) launch_updown_mfma<1>(h, a, pg, grid, lds, deriv, marg, nv);
+        else if (T == 2) launch_updown_mfma<2>(h, a, pg, grid, lds, deriv, marg, nv);
+        else if (T == 3) launch_updown_mfma<3>(h, a, pg, grid, lds, deriv, marg, nv);
+        else launch_updown_mfma<4>(h, a, pg, grid, lds, deriv, marg, nv);
         if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;
@@ -2103,11 +2122,10 @@ static bool use_updown_vec(const plk_engine *h)
 }
 
 template <int K>
-static void launch_updown_vec(plk_engine *h, const UpVecArgs &a, const int *d_obs, unsigned grid, bool deriv, bool marg, bool nodes)
+static void launch_updown_vec(plk_engine *h, const UpVecArgs &a, const int *d_obs, unsigned grid, bool deriv, bool marg)
 {
     hipLaunchKernelGGL(k_down_vec<K>, dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a, d_obs);
-    if (nodes) hipLaunchKernelGGL(k_up_nodes<K>, dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
-    else if (deriv && marg) hipLaunchKernelGGL((k_up_vec<K, true, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
+    if (deriv && marg) hipLaunchKernelGGL((k_up_vec<K, true, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
     else if (deriv) hipLaunchKernelGGL((k_up_vec<K, true, false>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
     else hipLaunchKernelGGL((k_up_vec<K, false, true>), dim3(grid), dim3(UDV_BLOCK), 0, h->stream, a);
 }
@@ -2129,24 +2147,12 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
     PlkChain ch;
     plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
-    /* PLK_OPT_UP_NODES = 1: derivative queries without marginals take the node-visit up pass (k_up_nodes: a third of
-     * the HBM reads, but two waves per SIMD -- 60 ms against 28 ms per million sites at BASELINE config 4, so not the
-     * default) */
-    const bool nodes = deriv && !marg && h->opt_up_nodes;
     PlkUpVisits uv;
+    plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                        node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
     {
         std::string bad = plk_chain_check(N, h->pg, ch, 3, INT_MAX, nin, nie, nsc, 0, 0);
-        if (nodes) {
-            PlkUpNodes un;
-            plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                               node_int.data(), node_scale.data(), edge_mask, un);
-            if (bad.empty()) bad = plk_up_nodes_check(N, E, un, nin, ntips, nsc);
-            uv.rec.swap(un.rec); uv.kind.swap(un.kind); uv.edge.swap(un.edge); uv.nvisits = un.nvisits;
-        } else {
-            plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                                node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
-            if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
-        }
+        if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
     const int nstream = (int)uv.kind.size();
@@ -2215,8 +2221,8 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UDV_BLOCK - 1) / UDV_BLOCK);
-        if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg, nodes);
-        else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg, nodes);
+        if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg);
+        else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg);
         if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;

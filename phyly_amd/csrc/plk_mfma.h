@@ -25,8 +25,10 @@
 
 typedef double plk_d4 __attribute__((ext_vector_type(4)));
 
-#define MF_BLOCK 256           /* 4 waves = 64 sites per workgroup */
-#define MF_SITES 64
+#ifndef MF_BLOCK
+#define MF_BLOCK 256           /* 4 waves = 64 sites per workgroup (8 waves measured slower: profiles/r02_exp_codon_kernel_variants.json) */
+#endif
+#define MF_SITES (MF_BLOCK / 4)
 
 struct MfmaArgs {
     long S, Spad;

@@ -39,6 +39,9 @@ struct MUpArgs {
     double *LH;                   /* [n], at the common exponent Xmax */
     double *DV;                   /* [E][n] */
     double *MV;                   /* [N][k][n] */
+    /* node-visit up pass (k_up_nodes_mfma): records of plk_up_nodes_build(), and fragD holds the fragments of M^T */
+    const int *visits;
+    int nvisits;
 };
 
 template <int R>
@@ -63,6 +66,52 @@ __device__ static inline void mf_store(double *base, long stride, long lin, cons
     for (int r = 0; r < R; r++) base[(size_t)r * stride + lin] = v[r];
 }
 
+/* the same with the plane base pinned in an SGPR pair and the lane's index as a 32-bit offset: one VGPR addresses all
+ * R planes, where the forms above let the compiler keep R 64-bit lane addresses per array live across the loops
+ * (k_up_nodes_mfma<1>, vectors of 8 registers, needed 104 VGPRs with them) */
+template <int R>
+__device__ __forceinline__ void mfn_load(const double *base, long stride, long lin, double (&out)[R])
+{
+    const unsigned off = (unsigned)lin;
+    asm volatile("" : "+s"(base));
+#pragma unroll
+    for (int r = 0; r < R; r++) out[r] = (base + (size_t)r * stride)[off];
+}
+
+template <int R>
+__device__ __forceinline__ void mfn_store(double *base, long stride, long lin, const double (&v)[R])
+{
+    const unsigned off = (unsigned)lin;
+    asm volatile("" : "+s"(base));
+#pragma unroll
+    for (int r = 0; r < R; r++) (base + (size_t)r * stride)[off] = v[r];
+}
+
+/* table row of one pattern code: uniform base of the slot's table in SGPRs, the lane's (code, lane group) as a 32-bit offset */
+template <int R>
+__device__ __forceinline__ void mfn_gather(const double *tab, int nchar, int slot, unsigned ch, unsigned g, double (&out)[R])
+{
+    const double *base = tab + (size_t)slot * nchar * 4 * R;
+    asm volatile("" : "+s"(base));
+    const double2 *tp = reinterpret_cast<const double2 *>(base);
+    const unsigned off = ((ch * 4u + g) * (unsigned)R) >> 1;
+#pragma unroll
+    for (int r = 0; r < R; r += 2) { const double2 v = tp[off + (r >> 1)]; out[r] = v.x; out[r + 1] = v.y; }
+}
+/* pattern code of the lane's site at one node: row base in SGPRs, site as a 32-bit offset */
+__device__ __forceinline__ unsigned mfn_code(const uint8_t *codes, long Spad, long s0, int node, unsigned site)
+{
+    const uint8_t *row = codes + (size_t)node * Spad + s0;
+    asm volatile("" : "+s"(row));
+    return row[site];
+}
+template <class V>
+__device__ __forceinline__ V mfn_at(const V *base, unsigned off)
+{
+    asm volatile("" : "+s"(base));
+    return base[off];
+}
+
 /* all k states of the site equal? (the reference's exact constant-column test, src/arb_mat_extras.c:36-51) */
 template <int R>
 __device__ static inline bool mf_is_const(const double (&x)[R], int g, int k, double &x0)
@@ -77,6 +126,15 @@ __device__ static inline bool mf_is_const(const double (&x)[R], int g, int k, do
     return lo == hi;
 }
 
+/* mf_is_const with the lane-group index laundered through an empty asm: the 4T validity masks (g + 4r < k) are then
+ * recomputed at each call instead of being hoisted out of the visit loop, where they cost 2 SGPRs each and, once those
+ * ran out, spilled VGPR lanes and scratch (k_up_nodes_mfma<4>: 86 loop-invariant registers before this) */
+template <int R>
+__device__ __forceinline__ bool mfn_is_const(const double (&x)[R], int g, int k, double &x0)
+{
+    asm volatile("" : "+v"(g));
+    return mf_is_const<R>(x, g, k, x0);
+}
 /* y = M x with M given as A fragments already staged in LDS */
 template <int T>
 __device__ static inline void mf_matvec(const double *lds_frag, int kk4, int lane, const double (&x)[4 * T], double (&y)[4 * T])
@@ -205,7 +263,7 @@ struct MDownProg {
     double *slots;                /* [nslots][R][stride] */
 };
 
-template <int T>
+template <int T, bool STORE_L>
 __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_down_fused_mfma(MUpArgs a, MDownProg pg)
 {
     extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles, then nobs x 64 staged pattern codes */
@@ -236,7 +294,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
                 const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
-                mf_store<R>(a.LN + ((size_t)oz * a.C + c) * R * a.stride, a.stride, lin, x);
+                if (STORE_L) mf_store<R>(a.LN + ((size_t)oz * a.C + c) * R * a.stride, a.stride, lin, x);   /* the node-visit up pass reads edge vectors only */
                 mf_stage(lds_frag, a.fragP + ((size_t)c * a.E + oy) * nfrag, nfrag, tid);
                 double m[R], x0;
                 mf_matvec<T>(lds_frag, a.kk4, lane, x, m);
@@ -284,7 +342,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 }
             }
         }
-        mf_store<R>(a.LN + ((size_t)root_int * a.C + c) * R * a.stride, a.stride, lin, x);
+        if (STORE_L) mf_store<R>(a.LN + ((size_t)root_int * a.C + c) * R * a.stride, a.stride, lin, x);
         double lh_c = 0.0;
         const double *rw = a.root_wd + g * R;
 #pragma unroll
@@ -438,6 +496,153 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                     if (g + 4 * r < a.k && valid) a.MV[((size_t)b * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
             }
         }
+    }
+}
+
+/*
+ * Up pass of the derivative query by node visits (records: plk_up_nodes_build() of plk_program.h).
+ * k_up_mfma above reads, per internal edge, F_a, the sibling's edge vector and L_b: 81 GB per 500 k codon sites
+ * (rocprofv3 FETCH_SIZE, profiles/r02_cfg5_*), and the down pass writes both L_b and the edge vector P_b L_b for it.
+ * Here the down pass stores edge vectors only (k_down_fused_mfma<T, false>), and a visit of node a
+ *   - takes G_a (top of a's own edge) from registers or from FN,
+ *   - derivative of a's own edge = sum of (M_a^T G_a) o B_a o (all child messages) x s_a, the factors multiplied in one
+ *     at a time as they are read (stored edge vectors of internal children, tip-table rows of leaves); L_a is not read,
+ *   - F_a = P_a^T G_a, and for every child with work G_b = F_a o B_a o s_a o (the other children's messages): leaf
+ *     edges are finished with the edge-form tip tables, G_b of internal children is stored, except the last one,
+ *     which the next visit takes over in registers.
+ * Two products per internal node as before, a quarter of the reads.  a.fragD holds the fragments of M^T here.
+ *
+ * Register discipline: three vectors live at a time (gv / one product / one factor being read).  There is one code
+ * path for every node degree, every vector has one unconditional definition that dominates its uses, and a factor is
+ * read by one load sequence with selected (wave-uniform) base and step rather than by two arms of a branch: a vector
+ * written in both arms of a wave-uniform if / else is live from the top of the kernel for the register allocator (it
+ * sees a path around both arms).  All addressing is "SGPR base + 32-bit lane offset".  tools/vgpr_liveness.py
+ * prints the live sets this was tuned with.
+ */
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up_nodes_mfma(MUpArgs a)
+{
+    extern __shared__ double lds_frag[];
+    constexpr int R = 4 * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const long sl = (long)blockIdx.x * MF_SITES + wave * 16 + (lane & 15);
+    const bool valid = sl < a.n;
+    const unsigned slc = (unsigned)(valid ? sl : a.n - 1), ug = (unsigned)g;     /* 32-bit lane offsets: every base below is wave-uniform */
+    const long lin = ((long)blockIdx.x * MF_SITES + wave * 16) * 4 + lane;
+    const int nfrag = T * a.kk4 * 64;
+    const int NT = a.ntips + 1;
+    const size_t tabc = (size_t)NT * a.nchar * 4 * R;
+    const size_t n = (size_t)a.n;
+    const double inv = 1.0 / mfn_at(a.LH, slc);
+    const PLK_AS4 int *vis = as_uniform(a.visits);
+    const PLK_AS4 int *eint = as_uniform(a.edge_int);
+
+    for (int c = 0; c < a.C; c++) {
+        const double *tipc = a.tip + (size_t)c * tabc;
+        const double *dtipc = a.dtip + (size_t)c * tabc;
+        const double pc = as_uniform(a.cat_prior)[c] * mfn_at(a.CW + (size_t)c * n, slc);
+        const bool first_cat = c == 0, last_cat = c == a.C - 1;
+#define MUN_OUT_D(EDGE, VAL)                                                                              \
+        do { double t_ = (VAL); t_ += __shfl_xor(t_, 16, 64); t_ += __shfl_xor(t_, 32, 64);               \
+             if (valid && g == 0) { double *dp_ = a.DV + (size_t)(EDGE) * n; asm volatile("" : "+s"(dp_));  \
+                 dp_[slc] = (first_cat ? t_ : dp_[slc] + t_) * (last_cat ? inv : 1.0); } } while (0)
+        /* message of the child in record J into M: the tip-table row of its pattern code, or its stored edge vector */
+#define MUN_MESSAGE(J, M)                                                                                 \
+        do { const int b_ = ch[4 * (J)], t_ = ch[4 * (J) + 1], pos_ = ch[4 * (J) + 2] >> PLK_UN_POS_SHIFT; \
+             const unsigned cd_ = mfn_code(a.codes, a.Spad, a.s0, b_, slc);                                \
+             const bool tip_ = t_ >= 0;                                                                   \
+             const double *base_ = tip_ ? tipc + (size_t)t_ * a.nchar * 4 * R                            \
+                                        : a.EV + ((size_t)(tip_ ? 0 : eint[e0 + pos_]) * a.C + c) * R * a.stride; \
+             const size_t step_ = tip_ ? 1 : (size_t)a.stride;                                            \
+             const unsigned off_ = tip_ ? (cd_ * 4u + ug) * (unsigned)R : (unsigned)lin;                  \
+             _Pragma("unroll") for (int r = 0; r < R; r++) M[r] = mfn_at(base_ + (size_t)r * step_, off_); } while (0)
+        /* the node's own observation (tip-table slot ntips) */
+#define MUN_OWN(M)                                                                                        \
+        do { const unsigned cd_ = mfn_code(a.codes, a.Spad, a.s0, nd, slc);                                \
+             const double *base_ = tipc + (size_t)a.ntips * a.nchar * 4 * R;                              \
+             const unsigned off_ = (cd_ * 4u + ug) * (unsigned)R;                                          \
+             _Pragma("unroll") for (int r = 0; r < R; r++) M[r] = mfn_at(base_ + r, off_); } while (0)
+        double gv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) gv[r] = mfn_at(a.root_wd, ug * (unsigned)R + r);   /* the root's visit comes first and takes it from registers */
+        int vp = 0;
+        for (int v = 0; v < a.nvisits; v++) {
+            const int nd = vis[vp], deg = vis[vp + 1], nd_int = vis[vp + 2], slot = vis[vp + 3], hd = vis[vp + 4], e0 = vis[vp + 5];
+            const int ea = vis[vp + 6], hfl = vis[vp + 7];
+            const PLK_AS4 int *ch = vis + vp + 8;
+            vp += 8 + 4 * deg;
+            const double sc = slot >= 0 ? mfn_at(a.SC + ((size_t)slot * a.C + c) * n, slc) : 1.0;
+            if (!(hfl & PLK_UN_FROM_REGS)) mfn_load<R>(a.FN + ((size_t)nd_int * a.C + c) * R * a.stride, a.stride, lin, gv);
+            if (hfl & PLK_UN_OWN_D) {
+                double z[R], x0;
+                mf_stage(lds_frag, a.fragD + ((size_t)c * a.E + ea) * nfrag, nfrag, tid);
+                mf_matvec<T>(lds_frag, a.kk4, lane, gv, z);
+                /* (M_a^T G_a) . L_a with L_a = s_a B_a o (all messages), one factor at a time.  Zero row sums and every
+                 * factor constant (then L_a is): exactly zero, src/util.c:338-345 -- non-constant factors with a
+                 * constant product, which the reference would also zero, give a rounding-level value here */
+                bool cst = true;
+                if (hd) {
+                    double m[R];
+                    MUN_OWN(m);
+                    cst = mfn_is_const<R>(m, g, a.k, x0);
+#pragma unroll
+                    for (int r = 0; r < R; r++) z[r] *= m[r];
+                }
+                for (int j = 0; j < deg; j++) {
+                    double m[R];
+                    MUN_MESSAGE(j, m);
+                    cst = mfn_is_const<R>(m, g, a.k, x0) && cst;
+#pragma unroll
+                    for (int r = 0; r < R; r++) z[r] *= m[r];
+                }
+                double d = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; r++) d += z[r];
+                if (a.dzero && cst) d = 0.0;
+                MUN_OUT_D(ea, pc * sc * d);
+            }
+            /* F_a = P_a^T G_a; the root runs the same product (any edge's matrix) and then keeps its prior: one
+             * unconditional definition of fe */
+            double fe[R];
+            mf_stage(lds_frag, a.fragPT + ((size_t)c * a.E + (ea >= 0 ? ea : 0)) * nfrag, nfrag, tid);
+            mf_matvec<T>(lds_frag, a.kk4, lane, gv, fe);
+#pragma unroll
+            for (int r = 0; r < R; r++) fe[r] = (ea >= 0 ? fe[r] : gv[r]) * sc;
+            if (hd) {
+                double m[R];
+                MUN_OWN(m);
+#pragma unroll
+                for (int r = 0; r < R; r++) fe[r] *= m[r];
+            }
+            /* children in record order (the one that continues in registers is last); gv is re-formed whether or not
+             * anything continues */
+#pragma unroll
+            for (int r = 0; r < R; r++) gv[r] = fe[r];
+            for (int j = 0; j < deg; j++) {
+                const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
+                if (!(fl & PLK_UN_WORK)) continue;
+#pragma unroll
+                for (int r = 0; r < R; r++) gv[r] = fe[r];
+                for (int j2 = 0; j2 < deg; j2++) {
+                    if (j2 == j) continue;
+                    double m[R];
+                    MUN_MESSAGE(j2, m);
+#pragma unroll
+                    for (int r = 0; r < R; r++) gv[r] *= m[r];
+                }
+                if (fl & PLK_UN_LEAF_D) {
+                    double y[R], d = 0.0;
+                    const unsigned cd = mfn_code(a.codes, a.Spad, a.s0, b, slc);
+                    mfn_gather<R>(dtipc, a.nchar, t, cd, ug, y);
+#pragma unroll
+                    for (int r = 0; r < R; r++) d = fma(gv[r], y[r], d);
+                    MUN_OUT_D(e0 + (fl >> PLK_UN_POS_SHIFT), pc * d);
+                } else if (fl & PLK_UN_STORE_G) mfn_store<R>(a.FN + ((size_t)bi * a.C + c) * R * a.stride, a.stride, lin, gv);
+            }
+        }
+#undef MUN_OUT_D
+#undef MUN_MESSAGE
+#undef MUN_OWN
     }
 }
 

@@ -640,38 +640,32 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
 }
 
 /*
- * Node visits of k_up_nodes (plk_updown_vec.h): the derivative pass without marginals.  One visit per internal node a;
- * what is stored per internal node is the vector G_a at the TOP of the edge into a (forward vector of the parent with
- * the parent's observation, rescaling factor and the sibling messages folded in), not the forward vector at a.  The
- * visit computes the child messages once (L_b read once per internal child), the derivative of a's own edge from
- * G_a and the messages (L_a = product of the messages is not read), F_a = P_a^T G_a, and G_b for every child.
- * Visits are in depth-first order; the G of the last internal child that still has work below it is not stored but
- * handed to the next visit in registers (PLK_UN_CONTINUE on the child, PLK_UN_FROM_REGS on the next header).
+ * Node visits of k_up_nodes_mfma (plk_mfma_updown.h): the derivative pass without marginals.  One visit per internal
+ * node a; what is stored per internal node is the vector G_a at the TOP of the edge into a (forward vector of the
+ * parent with the parent's observation, rescaling factor and the sibling messages folded in), not the forward vector
+ * at a.  A visit finishes the derivative of a's own edge from G_a and the child messages (stored edge vectors / tip
+ * tables; L_a is not read), forms F_a = P_a^T G_a and the G_b of every child.  Visits are in depth-first order; the G
+ * of the last internal child that still has work below it is not stored but handed to the next visit in registers
+ * (PLK_UN_CONTINUE on the child -- always the LAST child record -- and PLK_UN_FROM_REGS on the next header).
  *   header (8 ints): node, number of children, storage index, rescaling slot or -1, has_data, first CSR edge,
- *                    CSR edge into the node (-1: root), PLK_UN_* header flags
- *   child (4 ints):  node, tip slot or -1, PLK_UN_* child flags, storage index (internal child) or -1
- * Matrix stream (kinds as k_build_up_stream: 0 transposed P, 2 plain P, 3 plain edge form, 4 identity -- the root's
- * "own edge": its visit is the first, flagged PLK_UN_FROM_REGS, and the kernel starts with the root prior in registers):
- *   node with at most two factors besides F_a (two children, or one child and an observation of its own): kind 0 of every
- *     internal child in order; then for a non-root node kind 3 of its own edge (PLK_UN_OWN_D) and kind 2 of its own edge
- *     (always: the kernel forms F_a unconditionally, so that no vector is defined on some paths only);
- *   node with more factors (PLK_UN_MANY): kind 3 / kind 2 of its own edge as above, then, for every child with work,
- *     kind 0 of each internal sibling.
+ *                    CSR edge into the node (-1: root, whose visit is the first and takes the root prior from
+ *                    registers), PLK_UN_* header flags
+ *   child (4 ints):  node, tip slot or -1, PLK_UN_* child flags | position among the node's CSR children << 4,
+ *                    storage index (internal child) or -1
  */
-enum { PLK_UN_OWN_D = 1, PLK_UN_FROM_REGS = 2, PLK_UN_NEED_F = 4, PLK_UN_MANY = 8 };          /* header flags */
-enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4 };                           /* child flags */
+enum { PLK_UN_OWN_D = 1, PLK_UN_FROM_REGS = 2 };                                              /* header flags */
+enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_POS_SHIFT = 4 };   /* child flags */
 
 struct PlkUpNodes {
     std::vector<int> rec;
     int nvisits = 0;
-    std::vector<int> kind, edge;       /* the matrix stream */
 };
 
 static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
                                       const int *edge_tip, const int *node_int, const int *node_scale, const int *edge_mask,
                                       PlkUpNodes &un)
 {
-    un.rec.clear(); un.kind.clear(); un.edge.clear(); un.nvisits = 0;
+    un.rec.clear(); un.nvisits = 0;
     std::vector<int> edge_into(N, -1);
     for (int a = 0; a < N; a++) for (int idx = ip[a]; idx < ip[a + 1]; idx++) edge_into[ix[idx]] = idx;
     auto wanted = [&](int idx) { return !edge_mask || edge_mask[idx]; };
@@ -682,7 +676,6 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
         for (int idx = ip[a]; idx < ip[a + 1]; idx++) if (sub[ix[idx]]) below[a] = 1;
         sub[a] = below[a] || (edge_into[a] >= 0 && wanted(edge_into[a]));
     }
-    auto put = [&](int kind, int edge) { un.kind.push_back(kind); un.edge.push_back(edge); };
     std::vector<int> stack;
     const int root = preorder[0];
     if (ip[root + 1] > ip[root] && sub[root]) stack.push_back(root);
@@ -691,102 +684,74 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
         int a;
         if (from_regs >= 0) a = from_regs; else { a = stack.back(); stack.pop_back(); }
         const int start = ip[a], deg = ip[a + 1] - start, ea = edge_into[a];
-        const bool many = deg > 2 || (deg == 2 && node_has_data[a]);     /* more than two factors besides F_a */
-        int hfl = (ea >= 0 && wanted(ea) ? PLK_UN_OWN_D : 0) | (from_regs >= 0 || ea < 0 ? PLK_UN_FROM_REGS : 0) |
-                  (below[a] ? PLK_UN_NEED_F : 0) | (many ? PLK_UN_MANY : 0);
+        const int hfl = (ea >= 0 && wanted(ea) ? PLK_UN_OWN_D : 0) | (from_regs >= 0 || ea < 0 ? PLK_UN_FROM_REGS : 0);
         from_regs = -1;
         const int hdr[8] = {a, deg, node_int[a], node_scale[a], node_has_data[a] ? 1 : 0, start, ea, hfl};
         un.rec.insert(un.rec.end(), hdr, hdr + 8);
-        /* the child that continues in registers: the last internal child with work (never below a node with many children) */
+        /* the child that continues in registers: the last internal child with work; its record goes last */
         int cont = -1;
-        if (!many && below[a])
-            for (int j = 0; j < deg; j++) if (edge_tip[start + j] < 0 && sub[ix[start + j]]) cont = j;
-        std::vector<int> cfl(deg, 0);
-        for (int j = 0; j < deg; j++) {
-            const int idx = start + j, b = ix[idx];
-            const bool leaf = edge_tip[idx] >= 0;
-            if (below[a]) {
-                if (leaf) cfl[j] = wanted(idx) ? PLK_UN_LEAF_D : 0;
-                else if (sub[b]) cfl[j] = j == cont ? PLK_UN_CONTINUE : PLK_UN_STORE_G;
-            }
-            const int cr[4] = {b, edge_tip[idx], cfl[j], leaf ? -1 : node_int[b]};
-            un.rec.insert(un.rec.end(), cr, cr + 4);
-        }
-        un.nvisits++;
-        if (!many) {
-            for (int j = 0; j < deg; j++) if (edge_tip[start + j] < 0) put(0, start + j);
-            if (ea >= 0 && (hfl & PLK_UN_OWN_D)) put(3, ea);
-            put(ea >= 0 ? 2 : 4, ea >= 0 ? ea : 0);
-        } else {
-            if (ea >= 0 && (hfl & PLK_UN_OWN_D)) put(3, ea);
-            put(ea >= 0 ? 2 : 4, ea >= 0 ? ea : 0);
+        if (below[a]) for (int j = 0; j < deg; j++) if (edge_tip[start + j] < 0 && sub[ix[start + j]]) cont = j;
+        for (int pass = 0; pass < 2; pass++)
             for (int j = 0; j < deg; j++) {
-                if (!cfl[j]) continue;
-                for (int j2 = 0; j2 < deg; j2++) if (j2 != j && edge_tip[start + j2] < 0) put(0, start + j2);
+                if ((j == cont) != (pass == 1)) continue;
+                const int idx = start + j, b = ix[idx];
+                const bool leaf = edge_tip[idx] >= 0;
+                int fl = 0;
+                if (below[a]) {
+                    if (leaf) fl = wanted(idx) ? PLK_UN_LEAF_D : 0;
+                    else if (sub[b]) fl = j == cont ? PLK_UN_CONTINUE : PLK_UN_STORE_G;
+                }
+                const int cr[4] = {b, edge_tip[idx], fl | (j << PLK_UN_POS_SHIFT), leaf ? -1 : node_int[b]};
+                un.rec.insert(un.rec.end(), cr, cr + 4);
             }
-        }
+        un.nvisits++;
         /* stored children are visited later (depth first: the most recently stored first), the continued one next */
-        for (int j = 0; j < deg; j++) if (cfl[j] & PLK_UN_STORE_G) stack.push_back(ix[start + j]);
+        for (int j = 0; j < deg; j++) if (j != cont && edge_tip[start + j] < 0 && below[a] && sub[ix[start + j]]) stack.push_back(ix[start + j]);
         if (cont >= 0) from_regs = ix[start + cont];
     }
 }
 
-/* replays k_up_nodes' walk: indices in range, every G read after it was written (or handed over in registers by the
- * visit just before), the matrices consumed are exactly the list, in order */
-static inline std::string plk_up_nodes_check(int N, int E, const PlkUpNodes &un, int nint_nodes, int ntips, int nscale_slots)
+/* replays the kernel's walk: indices in range, every child position once, every G read after it was written (or
+ * handed over in registers by the visit just before) */
+static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const int *ix, const PlkUpNodes &un, int nint_nodes, int ntips,
+                                             int nscale_slots)
 {
     std::vector<char> g_written(std::max(nint_nodes, 1), 0), visited(N, 0);
-    size_t vp = 0, ms = 0;
+    size_t vp = 0;
     int handed = -1;                     /* node whose G is in registers */
     for (int v = 0; v < un.nvisits; v++) {
         if (vp + 8 > un.rec.size()) return "up nodes: record overrun";
         const int *h = &un.rec[vp];
         const int a = h[0], deg = h[1], ai = h[2], slot = h[3], e0 = h[5], ea = h[6], hfl = h[7];
         if (a < 0 || a >= N || deg < 1 || ai < 0 || ai >= nint_nodes || slot < -1 || slot >= nscale_slots) return plk_fmt("up nodes: bad header %ld", v);
-        if (e0 < 0 || e0 + deg > E || ea < -1 || ea >= E) return plk_fmt("up nodes: bad edge range in visit %ld", v);
+        if (e0 != ip[a] || deg != ip[a + 1] - ip[a] || e0 + deg > E || ea < -1 || ea >= E || (ea >= 0 && ix[ea] != a)) return plk_fmt("up nodes: bad edge range in visit %ld", v);
         if (vp + 8 + 4 * (size_t)deg > un.rec.size()) return "up nodes: record overrun";
         if (visited[a]) return plk_fmt("up nodes: node %ld visited twice", a);
         visited[a] = 1;
-        if (((hfl & PLK_UN_MANY) != 0) != (deg > 2 || (deg == 2 && h[4]))) return plk_fmt("up nodes: degree flag of visit %ld", v);
         if (ea < 0) { if (v != 0 || !(hfl & PLK_UN_FROM_REGS) || handed >= 0) return "up nodes: the root's visit must be the first and take its vector from registers"; }
         else if (hfl & PLK_UN_FROM_REGS) { if (handed != a) return plk_fmt("up nodes: visit %ld expects a vector in registers that the previous visit did not leave", v); }
         else if (handed >= 0) return plk_fmt("up nodes: the vector left in registers before visit %ld is dropped", v);
-        else if (ea >= 0 && !g_written[ai]) return plk_fmt("up nodes: vector of node %ld read before it is written", a);
+        else if (!g_written[ai]) return plk_fmt("up nodes: vector of node %ld read before it is written", a);
         if (ea < 0 && (hfl & PLK_UN_OWN_D)) return "up nodes: the root has no edge";
         handed = -1;
         const int *ch = h + 8;
-        auto need = [&](int kind, int edge) -> bool { const bool ok = ms < un.kind.size() && un.kind[ms] == kind && un.edge[ms] == edge; ms++; return ok; };
-        int ncont = 0;
+        std::vector<char> seen(deg, 0);
         for (int j = 0; j < deg; j++) {
-            const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
-            if (b < 0 || b >= N || t < -1 || t >= ntips) return plk_fmt("up nodes: bad child in visit %ld", v);
+            const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2] & ((1 << PLK_UN_POS_SHIFT) - 1), pos = ch[4 * j + 2] >> PLK_UN_POS_SHIFT, bi = ch[4 * j + 3];
+            if (pos < 0 || pos >= deg || seen[pos]) return plk_fmt("up nodes: child positions of visit %ld", v);
+            seen[pos] = 1;
+            if (b != ix[e0 + pos] || t < -1 || t >= ntips) return plk_fmt("up nodes: bad child in visit %ld", v);
             if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up nodes: bad storage index in visit %ld", v);
             if (t >= 0 && (fl & (PLK_UN_STORE_G | PLK_UN_CONTINUE))) return plk_fmt("up nodes: a leaf gets a stored vector in visit %ld", v);
             if (t < 0 && (fl & PLK_UN_LEAF_D)) return plk_fmt("up nodes: leaf flag on an internal child in visit %ld", v);
-            if (fl && !(hfl & PLK_UN_NEED_F)) return plk_fmt("up nodes: child work without the forward vector in visit %ld", v);
-            if (fl & PLK_UN_CONTINUE) { ncont++; handed = b; if ((hfl & PLK_UN_MANY) || (fl & PLK_UN_STORE_G)) return plk_fmt("up nodes: bad continuation in visit %ld", v); }
+            if ((fl & PLK_UN_CONTINUE) && (j != deg - 1 || (fl & PLK_UN_STORE_G))) return plk_fmt("up nodes: the continued child must be the last record of visit %ld", v);
+            if (fl & PLK_UN_CONTINUE) handed = b;
+            if (fl & PLK_UN_STORE_G) g_written[bi] = 1;
         }
-        if (ncont > 1) return plk_fmt("up nodes: two continuations in visit %ld", v);
-        if (!(hfl & PLK_UN_MANY)) {
-            for (int j = 0; j < deg; j++) if (ch[4 * j + 1] < 0 && !need(0, e0 + j)) return plk_fmt("up nodes: stream mismatch (message) in visit %ld", v);
-            if (ea >= 0 && (hfl & PLK_UN_OWN_D) && !need(3, ea)) return plk_fmt("up nodes: stream mismatch (edge form) in visit %ld", v);
-            if (!need(ea >= 0 ? 2 : 4, ea >= 0 ? ea : 0)) return plk_fmt("up nodes: stream mismatch (forward) in visit %ld", v);
-        } else {
-            if (ea >= 0 && (hfl & PLK_UN_OWN_D) && !need(3, ea)) return plk_fmt("up nodes: stream mismatch (edge form) in visit %ld", v);
-            if (!need(ea >= 0 ? 2 : 4, ea >= 0 ? ea : 0)) return plk_fmt("up nodes: stream mismatch (forward) in visit %ld", v);
-            for (int j = 0; j < deg; j++) {
-                if (!ch[4 * j + 2]) continue;
-                for (int j2 = 0; j2 < deg; j2++)
-                    if (j2 != j && ch[4 * j2 + 1] < 0 && !need(0, e0 + j2)) return plk_fmt("up nodes: stream mismatch (sibling) in visit %ld", v);
-            }
-        }
-        for (int j = 0; j < deg; j++) if (ch[4 * j + 2] & PLK_UN_STORE_G) g_written[ch[4 * j + 3]] = 1;
         vp += 8 + 4 * (size_t)deg;
     }
     if (handed >= 0) return "up nodes: a vector is left in registers at the end";
     if (vp != un.rec.size()) return "up nodes: trailing records";
-    if (ms != un.kind.size()) return "up nodes: matrix stream not consumed";
-    for (size_t i = 0; i < un.edge.size(); i++) if (un.edge[i] < 0 || un.edge[i] >= E || (un.kind[i] != 0 && un.kind[i] < 2) || un.kind[i] > 4) return "up nodes: bad stream entry";
     return "";
 }
 

@@ -101,18 +101,6 @@ __device__ __forceinline__ bool udv_const(const double (&x)[K], int k)
         if (i < k) diff |= ((unsigned)__double2loint(x[i]) ^ lo0) | ((unsigned)__double2hiint(x[i]) ^ hi0);
     return diff == 0;
 }
-/* a wave-uniform pointer the backend chose to keep in VGPRs (it does when an SGPR loop variable meets a vector-side
- * copy) back into an SGPR pair: the products' asm takes its matrix as an "s" operand and the compiler substitutes the
- * VGPR pair into s_load otherwise, which does not assemble */
-__device__ __forceinline__ const PLK_AS4 double *udv_sgpr(const PLK_AS4 double *p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const PLK_AS4 double *)(((unsigned long long)hi << 32) | lo);
-}
-/* orders the computation of x before every later asm volatile statement (the products): without it the scheduler lets a
- * reduction over one product's result sink below the next product, and both results are live at once */
-__device__ __forceinline__ void udv_pin(double &x) { asm volatile("" : "+v"(x) : : "memory"); }   /* and no load moves up across it */
 /* ---------------------------------------------------------------------------------------------------------- */
 template <int K>
 __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *__restrict__ obs_nodes)
@@ -409,182 +397,6 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
 }
 
-/*
- * Up pass of the derivative query, node visits (plk_up_nodes_build() of plk_program.h is the other half of the contract).
- * The one-edge-at-a-time kernel above reads F_a for every child, L_b as the child's own vector AND as its sibling's
- * message: 141 GB of HBM reads per million sites at BASELINE config 4 (rocprofv3 FETCH_SIZE, profiles/r02_*), which is
- * what bounded it.  Here a visit of node a
- *   - computes every child message once (one read of L_b per internal child),
- *   - takes G_a, the vector at the top of a's own edge, from registers (the previous visit left it) or from FN,
- *   - finishes the derivative of a's own edge as (M_a^T G_a) . L_a with L_a = product of the messages (not read),
- *   - F_a = P_a^T G_a, and G_b = F_a o s_a o (the other factor) for every child: leaf edges are finished with the
- *     edge-form tip tables, the G of internal children is stored to FN -- except the last one, which the next visit uses.
- * Per internal node: one L read, and one G write + read only where the tree forks into two internal children.
- *
- * Register discipline (K = 20: g, two messages and one product = 160 VGPRs + addressing).  Every vector has ONE
- * unconditional definition that dominates its uses: m0 / m1 start as ones, fe is always the product with the stream's
- * next matrix (the root's is an identity, kind 4, and its g is the root prior), and g is re-formed at the end of every
- * visit whether or not a child continues.  A vector defined only in the arms of wave-uniform branches is treated by
- * the backend as live from the top of the kernel (it sees a path around both arms), which cost 80 registers in the
- * first version of this kernel; tools/vgpr_liveness.py prints the live sets.
- */
-template <int K>
-__global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_up_nodes(UpVecArgs a)
-{
-    const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
-    const bool valid = sl < a.n;
-    const long slc = valid ? sl : a.n - 1;
-    const long sg = a.s0 + slc;
-    const size_t n = (size_t)a.n;
-    const PLK_AS4 int *vis = as_uniform(a.visits);
-    const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
-    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
-    const double inv = 1.0 / a.LH[slc];
-    constexpr int KK = K * K;
-
-    for (int c = 0; c < a.C; c++) {
-        const double *tipc = a.tip + (size_t)c * tabc;
-        const double *dtipc = a.dtip + (size_t)c * tabc;
-        const PLK_AS4 double *ms = as_uniform(a.MS) + (size_t)c * (a.nstream + 3) * KK;
-        const double pc = prior[c] * a.CW[(size_t)c * n + slc];
-        const bool first_cat = c == 0, last_cat = c == a.C - 1;
-#define UDN_OUT_D(EDGE, VAL)                                                                              \
-        do { if (valid) { double *dp_ = a.DV + (size_t)(EDGE) * n + sl;                                   \
-             const double t_ = (VAL); *dp_ = (first_cat ? t_ : *dp_ + t_) * (last_cat ? inv : 1.0); } } while (0)
-        /* message of child J of the current visit into M (already defined): tip table row, or P_b L_b (one matrix of
-         * the stream; constant L_b: the constant, src/util.c:276-283) */
-#define UDN_MESSAGE(J, M)                                                                                 \
-        do { const int b_ = ch[4 * (J)], t_ = ch[4 * (J) + 1];                                            \
-             if (t_ >= 0) udv_gather<K>(tipc + ((size_t)t_ * a.nchar + a.codes[(size_t)b_ * a.Spad + sg]) * K, M); \
-             else { double L_[K];                                                                         \
-                    udv_load<K>(a.LN + ((size_t)ch[4 * (J) + 3] * a.C + c) * K * n, n, slc, L_);          \
-                    { const PLK_AS4 double *mp_ = udv_sgpr(ms); vec_touch<K>(mp_ + 2 * KK); vec_matvec<K>(mp_, L_, M); } ms += KK;                        \
-                    if (udv_const<K>(L_, a.k)) { const double x0_ = L_[0];                                \
-                        _Pragma("unroll") for (int i = 0; i < K; i++) M[i] = i < a.k ? x0_ : 0.0; } } } while (0)
-        double g[K];
-#pragma unroll
-        for (int i = 0; i < K; i++) g[i] = rw[i];                 /* the root's visit comes first and takes g from registers */
-        int vp = 0;
-        for (int v = 0; v < a.nvisits; v++) {
-            const int nd = vis[vp], deg = vis[vp + 1], nd_int = vis[vp + 2], slot = vis[vp + 3], hd = vis[vp + 4], e0 = vis[vp + 5];
-            const int ea = vis[vp + 6], hfl = vis[vp + 7];
-            const PLK_AS4 int *ch = vis + vp + 8;
-            vp += 8 + 4 * deg;
-            const double sc = slot >= 0 ? a.SC[((size_t)slot * a.C + c) * n + slc] : 1.0;
-            if (!(hfl & PLK_UN_MANY)) {
-                /* two factors besides F_a: the messages of two children, or of one child and the node's own observation */
-                double m0[K], m1[K], fe[K];
-#pragma unroll
-                for (int i = 0; i < K; i++) { m0[i] = 1.0; m1[i] = 1.0; }
-                UDN_MESSAGE(0, m0);
-                if (deg == 2) UDN_MESSAGE(1, m1);
-                else if (hd) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * K, m1);
-                if (!(hfl & PLK_UN_FROM_REGS)) udv_load<K>(a.FN + ((size_t)nd_int * a.C + c) * K * n, n, slc, g);
-                if (hfl & PLK_UN_OWN_D) {
-                    double z[K];
-                    { const PLK_AS4 double *mp_ = udv_sgpr(ms); vec_touch<K>(mp_ + 2 * KK); vec_matvec<K>(mp_, g, z); } ms += KK;
-                    /* L_a = s_a (m0 o m1), entry by entry; constant L_a and zero row sums: exactly zero (src/util.c:338-345) */
-                    double d = 0.0;
-#pragma unroll
-                    for (int i = 0; i < K; i++) d = fma(z[i], m0[i] * m1[i], d);
-                    udv_pin(d);                                   /* z is dead from here */
-                    const double l0 = m0[0] * m1[0];
-                    unsigned diff = 0;
-#pragma unroll
-                    for (int i = 1; i < K; i++) {
-                        const double l = m0[i] * m1[i];
-                        const unsigned in_k = i < a.k ? ~0u : 0u;     /* wave-uniform mask, no branch per entry */
-                        diff |= (((unsigned)__double2loint(l) ^ (unsigned)__double2loint(l0)) | ((unsigned)__double2hiint(l) ^ (unsigned)__double2hiint(l0))) & in_k;
-                    }
-                    if (a.dzero && diff == 0) d = 0.0;
-                    udv_pin(d);
-                    UDN_OUT_D(ea, pc * sc * d);
-                }
-                { const PLK_AS4 double *mp_ = udv_sgpr(ms); vec_touch<K>(mp_ + 2 * KK); vec_matvec<K>(mp_, g, fe); } ms += KK;       /* P_a^T G_a; identity at the root */
-#pragma unroll
-                for (int i = 0; i < K; i++) fe[i] *= sc;
-                /* child 0 sees m1, child 1 sees m0 */
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if (j >= deg) break;
-                    const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
-                    double (&mo)[K] = j == 0 ? m1 : m0;
-                    if (fl & PLK_UN_LEAF_D) {
-                        double y[K], d = 0.0;
-                        udv_gather<K>(dtipc + ((size_t)t * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, y);
-#pragma unroll
-                        for (int i = 0; i < K; i++) d = fma(fe[i] * mo[i], y[i], d);
-                        udv_pin(d);
-                        UDN_OUT_D(e0 + j, pc * d);
-                    } else if (fl & PLK_UN_STORE_G) {
-                        double gb[K];
-#pragma unroll
-                        for (int i = 0; i < K; i++) gb[i] = fe[i] * mo[i];
-                        if (valid) udv_store<K>(a.FN + ((size_t)bi * a.C + c) * K * n, n, slc, gb);
-                    }
-                }
-                /* the vector for the next visit: child 1's when PLK_UN_CONTINUE is on child 1, else child 0's (formed also
-                 * when nothing continues: an unconditional definition ends g's live range at the product above) */
-                const bool second = deg == 2 && (ch[4 + 2] & PLK_UN_CONTINUE);
-#pragma unroll
-                for (int i = 0; i < K; i++) g[i] = fe[i] * (second ? m0[i] : m1[i]);
-            } else {
-                /* more than two factors: the messages do not fit in registers together; L_a is read, and the sibling
-                 * messages are recomputed for every child with work (as the one-edge-at-a-time kernel does) */
-                double fe[K];
-                if (!(hfl & PLK_UN_FROM_REGS)) udv_load<K>(a.FN + ((size_t)nd_int * a.C + c) * K * n, n, slc, g);
-                if (hfl & PLK_UN_OWN_D) {
-                    double z[K], L[K], d = 0.0;
-                    { const PLK_AS4 double *mp_ = udv_sgpr(ms); vec_touch<K>(mp_ + 2 * KK); vec_matvec<K>(mp_, g, z); } ms += KK;
-                    udv_load<K>(a.LN + ((size_t)nd_int * a.C + c) * K * n, n, slc, L);
-#pragma unroll
-                    for (int i = 0; i < K; i++) d = fma(z[i], L[i], d);
-                    if (a.dzero && udv_const<K>(L, a.k)) d = 0.0;
-                    udv_pin(d);
-                    UDN_OUT_D(ea, pc * d);
-                }
-                { const PLK_AS4 double *mp_ = udv_sgpr(ms); vec_touch<K>(mp_ + 2 * KK); vec_matvec<K>(mp_, g, fe); } ms += KK;
-#pragma unroll
-                for (int i = 0; i < K; i++) g[i] = fe[i];          /* nothing continues below such a node; defined all the same */
-                if (hd) {
-                    double bv[K];
-                    udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)nd * a.Spad + sg]) * K, bv);
-#pragma unroll
-                    for (int i = 0; i < K; i++) fe[i] *= bv[i];
-                }
-#pragma unroll
-                for (int i = 0; i < K; i++) fe[i] *= sc;
-                for (int j = 0; j < deg; j++) {
-                    const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2], bi = ch[4 * j + 3];
-                    if (!fl) continue;
-                    double gb[K];
-#pragma unroll
-                    for (int i = 0; i < K; i++) gb[i] = fe[i];
-                    for (int j2 = 0; j2 < deg; j2++) {
-                        if (j2 == j) continue;
-                        double m[K];
-#pragma unroll
-                        for (int i = 0; i < K; i++) m[i] = 1.0;
-                        UDN_MESSAGE(j2, m);
-#pragma unroll
-                        for (int i = 0; i < K; i++) gb[i] *= m[i];
-                    }
-                    if (fl & PLK_UN_LEAF_D) {
-                        double y[K], d = 0.0;
-                        udv_gather<K>(dtipc + ((size_t)t * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, y);
-#pragma unroll
-                        for (int i = 0; i < K; i++) d = fma(gb[i], y[i], d);
-                        udv_pin(d);
-                        UDN_OUT_D(e0 + j, pc * d);
-                    } else if (valid) udv_store<K>(a.FN + ((size_t)bi * a.C + c) * K * n, n, slc, gb);
-                }
-            }
-        }
-#undef UDN_OUT_D
-#undef UDN_MESSAGE
-    }
-}
-
 /* dtip[((c*(ntips+1) + t)*nchar + code)*K + i] = (M_e defs[code])[i] in double-double; zero for constant definition
  * rows when the matrices have zero row sums (src/util.c:338-345); slot ntips unused (zeros) */
 __global__ void k_build_dtip_vec(int k, int K, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
@@ -612,20 +424,18 @@ __global__ void k_build_dtip_vec(int k, int K, int E, int ntips, int nchar, cons
 }
 
 /* matrix stream of the up pass: MS[c][slot] = matrix kind[slot] of edge edge[slot]; kind 0: transposed P (PT layout:
- * out[j*K+i] = P[i][j]), 1: transposed M (edge form), 2: plain P (out[i*K+j] = P[i][j]), 3: plain M, 4: identity; slots nstream .. nstream+2:
- * zeros */
+ * out[j*K+i] = P[i][j]), 1: transposed M (edge form), 2: plain P (out[i*K+j] = P[i][j]); slots nstream .. nstream+2: zeros */
 __global__ void k_build_up_stream(int k, int K, int E, int nstream, const int *__restrict__ kind, const int *__restrict__ edge,
                                   const double *__restrict__ P, const double *__restrict__ M, double *__restrict__ MS)
 {
     const int slot = blockIdx.x, c = blockIdx.y;
     double *dst = MS + ((size_t)c * (nstream + 3) + slot) * K * K;
     const int kd = slot < nstream ? kind[slot] : -1;
-    const double *src = kd < 0 ? nullptr : (kd == 1 || kd == 3 ? M : P) + ((size_t)c * E + edge[slot < nstream ? slot : 0]) * k * k;
+    const double *src = kd < 0 ? nullptr : (kd == 1 ? M : P) + ((size_t)c * E + edge[slot < nstream ? slot : 0]) * k * k;
     for (int idx = threadIdx.x; idx < K * K; idx += blockDim.x) {
         const int r = idx / K, q = idx - r * K;
         double v = 0.0;
-        if (kd == 4) v = r == q && r < k ? 1.0 : 0.0;
-        else if (kd >= 0 && r < k && q < k) v = kd >= 2 ? src[r * k + q] : src[q * k + r];
+        if (kd >= 0 && r < k && q < k) v = kd == 2 ? src[r * k + q] : src[q * k + r];
         dst[idx] = v;
     }
 }

@@ -224,9 +224,10 @@ def test_medium_and_large_state_spaces(oracle, k):
     full = json.dumps({"model_and_data": md})
     few = json.dumps({"model_and_data": md, "edge_reduction": {"selection": [0, 3, 3, n_nodes - 2]}})
     _check("deriv", json.loads(arbplf.arbplf_deriv(few)), json.loads(oracle.arbplf_deriv(few)))
-    if k <= 20:
-        # the same two queries through the arbplf-deriv executable with the node-visit up pass (k_up_nodes, opt-in):
-        # random trees here have multifurcations, unary nodes and data at internal nodes, and two rate categories
+    if k > 20:
+        # matrix-core kernels: the same two queries through the arbplf-deriv executable with the node-visit up pass
+        # (k_up_nodes_mfma, ARBPLF_UP_NODES=1; the calls above took the default one-edge-at-a-time pass).  Random
+        # trees here have multifurcations, unary nodes and data at internal nodes, and there are two rate categories
         import os
         import subprocess
         exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phyly_amd", "csrc", "arbplf-deriv")
