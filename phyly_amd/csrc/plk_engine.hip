@@ -117,7 +117,7 @@ struct plk_engine {
     size_t u4pack_cap = 0, u4tip_cap = 0;
     double *d_stage = nullptr; size_t stage_cap = 0;   /* transposed per-site outputs on their way to the host */
     double *d_uvmat = nullptr; size_t uvmat_cap = 0;   /* vector down / up passes: PT and the up-pass matrix stream */
-    int mfma_first_slot = -1, mfma_first_row = 0, vec_second_row = 0;
+    int mfma_first_mv = -1, mfma_first_slot = -1, mfma_first_row = 0, vec_second_row = 0;
     size_t ps_cap = 0, tip_cap = 0;
 
     /* workspaces */
@@ -1497,6 +1497,8 @@ static int upload_formats(plk_engine *h, long kind)
                                                     (size_t)h->obs_nodes.size() * MF_SITES);
             if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
             h->mfma_first_slot = ch.first_slot; h->mfma_first_row = ch.first_row;
+            h->mfma_first_mv = -1;
+            for (size_t pc = 0; pc < h->pg.ops.size() && h->mfma_first_mv < 0; pc++) if ((h->pg.ops[pc].x & 0xff) == OP_MATVEC) h->mfma_first_mv = (int)pc;
             if ((rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(ch.ops.data()), ch.ops.size()))) return rc;
         }
     }
@@ -1646,7 +1648,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.kk4 = kk4; a.C = h->C; a.nops = nops; a.ntips = ntips;
         a.nchar = h->nchar; a.root_mode = h->root_mode; a.ops = h->d_mops; a.frag = h->d_frag; a.tip = h->d_tip;
         a.obs_nodes = h->d_obs_nodes; a.nobs = (int)h->obs_nodes.size();
-        a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row;
+        a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row; a.first_mv = h->mfma_first_mv;
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
         a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
         a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;

@@ -36,6 +36,7 @@ struct MfmaArgs {
     const int4 *ops;          /* x = opcode | tip<<8, y = staged code row (observation ops) / slot */
     const int *obs_nodes;     /* nobs nodes whose code rows are staged in LDS */
     int nobs, first_slot, first_row;   /* first observation op of the program (first_slot < 0: none) */
+    int first_mv;             /* op index of the first MATVEC (-1: none): its fragments are requested before the loop */
     const double *frag;       /* [C][nops][T][kk4][64] A fragments of P (zero padded) */
     const double *tip;        /* [C][ntips+1][nchar][4][4T]: [lane group][register], last slot = raw definitions */
     const uint8_t *codes;     /* [N][Spad] */
@@ -89,6 +90,28 @@ __device__ static inline void mf_stage(double *lds_frag, const double *src, int 
     __syncthreads();
 }
 
+/* The same in two halves around the previous product: mf_request() issues this lane's eight 16-byte loads of the NEXT
+ * matrix into registers and returns at once; mf_commit() -- after the product that still reads the current fragments --
+ * writes them to LDS between two barriers.  The L2 round trip of a staged matrix (longer than the 64 matrix-core
+ * instructions that consume it at k = 61) is then covered by the product before it, at the price of 32 VGPRs. */
+struct MfPending { double2 v[8]; };
+__device__ __forceinline__ void mf_request(MfPending &p, const double *src, int nfrag, int tid)
+{
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    const int n2 = nfrag / 2;
+#pragma unroll
+    for (int u = 0; u < 8; u++) p.v[u] = tid + u * MF_BLOCK < n2 ? s2[tid + u * MF_BLOCK] : double2{0.0, 0.0};
+}
+__device__ __forceinline__ void mf_commit(double *lds_frag, const MfPending &p, int nfrag, int tid)
+{
+    double2 *d2 = reinterpret_cast<double2 *>(lds_frag);
+    const int n2 = nfrag / 2;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (tid + u * MF_BLOCK < n2) d2[tid + u * MF_BLOCK] = p.v[u];
+    __syncthreads();
+}
+
 template <int T>
 __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
 {
@@ -111,6 +134,8 @@ __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
+    MfPending pend;
+    mf_request(pend, a.frag + (size_t)(a.first_mv >= 0 ? a.first_mv : 0) * nfrag, nfrag, tid);
 
     for (int c = 0; c < a.C; c++) {
         double x[R];
@@ -125,8 +150,11 @@ __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
             op.w = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 3];
             const int code = op.x & 0xff;
             if (code == OP_MATVEC) {
-                /* stage the A fragments of this edge (same for all 4 waves) */
-                mf_stage(lds_frag, a.frag + ((size_t)c * a.nops + pc) * nfrag, nfrag, tid);
+                /* the A fragments of this edge (same for all 4 waves) were requested before the previous product; put
+                 * them into LDS and request those of the next product (the next category's first one at the end) */
+                mf_commit(lds_frag, pend, nfrag, tid);
+                const int nc = op.z <= pc ? c + 1 : c;
+                mf_request(pend, a.frag + ((size_t)(nc < a.C ? nc : c) * a.nops + op.z) * nfrag, nfrag, tid);
                 plk_d4 acc[T];
 #pragma unroll
                 for (int t = 0; t < T; t++) acc[t] = (plk_d4){0.0, 0.0, 0.0, 0.0};

@@ -439,7 +439,7 @@ struct PlkChain {
 /* mode 3 (k_ll_vec, k_down_vec): as mode 1, and every observation op also carries in y the staged row of the observation
  * op AFTER the next one (the prefetch chain runs two ops ahead: value of the next op, code of the one after; the
  * sequence wraps to the start for the next category); MATVEC w = CSR edge of the next MATVEC.
- * mode 0: MATVEC keeps (x, y) of the program (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
+ * mode 0: MATVEC keeps (x, y) of the program, z = op index of the next MATVEC, wrapping (k_ll_mfma); mode 1: MATVEC y = CSR edge, z = storage index of the
  * child node, w = CSR edge of the next MATVEC, wrapping to the first (k_down_fused4, k_down_vec); mode 2: as 1 but
  * w = storage index of the edge (k_down_fused_mfma, no chain).  SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
 static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const int *indices, const int *node_int,
@@ -482,6 +482,17 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
         const size_t no = opc_.size();
         ch.second_row = no ? rows_[1 % no] : 0;
         for (size_t i = 0; i < no; i++) ch.ops[opc_[i]].y = rows_[(i + 2) % no];
+    }
+    if (mode == 0) {
+        /* MATVEC z = op index of the next MATVEC, wrapping to the first (k_ll_mfma requests its matrix fragments early) */
+        int first_mv = -1, prev_mv = -1;
+        for (size_t pc = 0; pc < pg.ops.size(); pc++)
+            if ((pg.ops[pc].x & 0xff) == OP_MATVEC) {
+                if (first_mv < 0) first_mv = (int)pc;
+                if (prev_mv >= 0) ch.ops[prev_mv].z = (int)pc;
+                prev_mv = (int)pc;
+            }
+        if (prev_mv >= 0) ch.ops[prev_mv].z = first_mv;
     }
     if (mode == 1 || mode == 3) {
         /* MATVEC w = CSR edge of the next MATVEC (wrapping); without node storage (ll kernels) z = its op index */
@@ -788,6 +799,11 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
                 cur_slot = ns; cur_row = o.w;
             }
             oi++;
+        } else if (code == OP_MATVEC && mode == 0) {
+            /* z = the next MATVEC's op index, cyclically */
+            int nx = (int)pc;
+            do { nx = nx + 1 < nops ? nx + 1 : 0; } while ((pg.ops[nx].x & 0xff) != OP_MATVEC);
+            if (o.z != nx) return plk_fmt("down program: op %ld names the wrong next product", pc);
         } else if (code == OP_MATVEC && mode >= 1) {
             if (o.y != pg.op_edge[pc] || o.z < 0 || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
             if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
