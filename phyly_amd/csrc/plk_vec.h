@@ -83,23 +83,12 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
     double sum = 0.0;
     int Eexp = 0;
     bool have = false;
-    /* Observation prefetch chain, two ops deep: while an observation op multiplies its tip-table row into the vector,
-     * the row of the NEXT observation op is already being gathered (its pattern code arrived during the previous op)
-     * and the code of the one after that is being loaded.  Without it every observation op waits for two dependent
-     * global loads (code, then table row): 200 of them per site at BASELINE config 4, more than the 198 products. */
+    /* Observation ops wait for two dependent global loads (pattern code, then its tip-table row).  The code of the NEXT
+     * observation op is requested one op ahead (one register); the two-ahead chain that also prefetches the row (K
+     * register pairs) is what k_down_vec uses, but here it cost a wave of occupancy (117 against 99 VGPRs) and 9 % of
+     * the speed (6.77 against 6.2 ms at BASELINE config 4). */
     const PLK_AS4 int *obs = as_uniform(a.obs_nodes);
-    double nv[K];
-    int code_next = 0;
-    if (a.first_slot >= 0) {
-        const int ch0 = a.codes[(size_t)obs[a.first_row] * a.Spad + sc];
-        const double2 *tp = reinterpret_cast<const double2 *>(a.tip + ((size_t)a.first_slot * a.nchar + ch0) * K);
-#pragma unroll
-        for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; nv[i] = v.x; nv[i + 1] = v.y; }
-        code_next = a.codes[(size_t)obs[a.second_row] * a.Spad + sc];
-    } else {
-#pragma unroll
-        for (int i = 0; i < K; i++) nv[i] = 1.0;
-    }
+    int code_next = a.first_slot >= 0 ? a.codes[(size_t)obs[a.first_row] * a.Spad + sc] : 0;
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -122,34 +111,31 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
 #pragma unroll
                 for (int i = 0; i < K; i++) cur[i] = acc[i];
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
-                const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
-                (void)ow;
+                const int ow = ops[4 * pc + 3];                     /* staged row of the next observation op (cyclic) */
+                const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
+                const double2 *tp = reinterpret_cast<const double2 *>(tipc + ((size_t)t * a.nchar + code_next) * K);
                 if (code == OP_TIP_SET) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) cur[i] = nv[i];
+                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] = v.x; cur[i + 1] = v.y; }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < K; i++) cur[i] *= nv[i];
+                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] *= v.x; cur[i + 1] *= v.y; }
                 }
-                /* next observation: its code is here, gather its row; then ask for the code of the one after */
-                const int wrap = (oz >> 30) & 1;
-                if (!wrap || c + 1 < a.C) {
-                    const double2 *tp = reinterpret_cast<const double2 *>(tipc + (size_t)wrap * tabc +
-                                                                          ((size_t)(oz & 0x3fffffff) * a.nchar + code_next) * K);
-#pragma unroll
-                    for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; nv[i] = v.x; nv[i + 1] = v.y; }
-                }
-                code_next = a.codes[(size_t)obs[oy] * a.Spad + sc];
+                code_next = a.codes[(size_t)obs[ow] * a.Spad + sc];
             } else if (code == OP_PUSH) {
-                double *sp = a.slots + (size_t)oy * K * a.S + sc;
+                /* plane base pinned in SGPRs, the lane's site as a 32-bit offset: otherwise the compiler keeps K 64-bit
+                 * lane addresses live across the loop (40 VGPRs at K = 20, a wave of occupancy) */
+                double *sp = a.slots + (size_t)oy * K * a.S;
+                asm volatile("" : "+s"(sp));
                 if (valid) {
 #pragma unroll
-                    for (int i = 0; i < K; i++) sp[(size_t)i * a.S] = cur[i];
+                    for (int i = 0; i < K; i++) (sp + (size_t)i * a.S)[(unsigned)sc] = cur[i];
                 }
             } else if (code == OP_POPMUL) {
-                const double *sp = a.slots + (size_t)oy * K * a.S + sc;
+                const double *sp = a.slots + (size_t)oy * K * a.S;
+                asm volatile("" : "+s"(sp));
 #pragma unroll
-                for (int i = 0; i < K; i++) cur[i] *= sp[(size_t)i * a.S];
+                for (int i = 0; i < K; i++) cur[i] *= (sp + (size_t)i * a.S)[(unsigned)sc];
             } else if (code == OP_SCALE) {
                 double m = 0.0;
 #pragma unroll
