@@ -1932,7 +1932,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * k * n;
-        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (deriv && edge_mask) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));   /* without a mask every edge's row is written by the up pass */
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
         a.visits = nodes ? pk + o_vis : nullptr; a.nvisits = un.nvisits;
@@ -2220,7 +2220,7 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
         a.MV = p; if (marg) p += (size_t)N * k * n;
-        if (deriv) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));
+        if (deriv && edge_mask) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));   /* without a mask every edge's row is written by the up pass */
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UDV_BLOCK - 1) / UDV_BLOCK);
         if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg);
