@@ -11,13 +11,14 @@
  *
  * Program format (built by prepare_stream_asm in plk_engine.hip): 32-bit op words in
  * blocks of 8, fetched a whole block ahead with one s_load_dwordx8;
- *   bits 2:0 opcode, bits 15:3 field y, bits 31:16 field z
+ *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 5 TIP_MUL without wait, 6 SCALE, 7 END, 8 + d PUSH to
+ *   stack slot d, 16 + d POPMUL of slot d), bits 15:5 field y, bits 31:16 field z
  *   MATVEC            x = P x; matrices are consumed in stream order, the next one is
  *                     requested as soon as the current one has been used
  *   TIP_SET / TIP_MUL x (*)= tip value of this observation, which was fetched from LDS
  *                     during the previous observation op; y = tip slot of the NEXT
  *                     observation op, z = code row of the one after next (prefetch chain)
- *   PUSH / POPMUL     y = stack slot in the accumulation registers
+ *   PUSH / POPMUL     the stack slot is part of the handler index
  *   SCALE             exact power-of-two rescale, exponent accumulated
  *   END
  * (an internal node with data is a TIP_MUL on the pseudo tip slot that holds the raw
@@ -32,94 +33,109 @@
  *   s[36:67] current P (transposed), FMA scalar operands
  *   s[68:75] current op block, s[76:83] next op block
  *   s[84:85] program pointer, s[86:87] matrix stream pointer, s[88:89] return address,
- *   s[90:91] dispatcher address, s92 LDS address of the tip table, s93 nchar*32,
+ *   s[90:91] address of handler 0 (handler i at + 256 i), s92 LDS address of the tip table, s93 nchar*32,
  *   s94 bytes per staged code row, s95 = -1022, s96 current op word, s97..s99 temps,
  *   s35 code field width (8, or 4 when codes are packed two per byte)
  */
 #ifndef PLK_FUSED4_ASM_H
 #define PLK_FUSED4_ASM_H
 
-#define PLK_ASM_POP(D_, R0, R1, R2, R3, R4, R5, R6, R7)                              \
-    ".Lpop" #D_ "_%=:\n\t"                                                           \
-    "v_accvgpr_read_b32 v32, a" #R0 "\n\tv_accvgpr_read_b32 v33, a" #R1 "\n\t"       \
-    "v_accvgpr_read_b32 v34, a" #R2 "\n\tv_accvgpr_read_b32 v35, a" #R3 "\n\t"       \
-    "v_accvgpr_read_b32 v36, a" #R4 "\n\tv_accvgpr_read_b32 v37, a" #R5 "\n\t"       \
-    "v_accvgpr_read_b32 v38, a" #R6 "\n\tv_accvgpr_read_b32 v39, a" #R7 "\n\t"       \
-    "s_branch .Lpopmul_%=\n"
-
-#define PLK_ASM_PUSH(D_, R0, R1, R2, R3, R4, R5, R6, R7)                             \
-    ".Lpush" #D_ "_%=:\n\t"                                                          \
-    "v_accvgpr_write_b32 a" #R0 ", v24\n\tv_accvgpr_write_b32 a" #R1 ", v25\n\t"     \
-    "v_accvgpr_write_b32 a" #R2 ", v26\n\tv_accvgpr_write_b32 a" #R3 ", v27\n\t"     \
-    "v_accvgpr_write_b32 a" #R4 ", v28\n\tv_accvgpr_write_b32 a" #R5 ", v29\n\t"     \
-    "v_accvgpr_write_b32 a" #R6 ", v30\n\tv_accvgpr_write_b32 a" #R7 ", v31\n\t"     \
-    "s_setpc_b64 s[88:89]\n"
-
-#define PLK_ASM_CALL(SREG) "s_mov_b32 s96, " #SREG "\n\ts_swappc_b64 s[88:89], s[90:91]\n\t"
-
-/* slot dispatch chains and bodies for 4 or 8 stack slots */
-#define PLK_ASM_POP_CHAIN4                                                            \
-    "s_cmp_eq_u32 s97, 0\n\ts_cbranch_scc1 .Lpop0_%=\n\t"                             \
-    "s_cmp_eq_u32 s97, 1\n\ts_cbranch_scc1 .Lpop1_%=\n\t"                             \
-    "s_cmp_eq_u32 s97, 2\n\ts_cbranch_scc1 .Lpop2_%=\n\t"
-#define PLK_ASM_POP_BODY4                                                             \
-    PLK_ASM_POP(0, 0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_POP(1, 8, 9, 10, 11, 12, 13, 14, 15)       \
-    PLK_ASM_POP(2, 16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_POP(3, 24, 25, 26, 27, 28, 29, 30, 31)
-#define PLK_ASM_PUSH_CHAIN4                                                           \
-    "s_cmp_eq_u32 s97, 0\n\ts_cbranch_scc1 .Lpush0_%=\n\t"                            \
-    "s_cmp_eq_u32 s97, 1\n\ts_cbranch_scc1 .Lpush1_%=\n\t"                            \
-    "s_cmp_eq_u32 s97, 2\n\ts_cbranch_scc1 .Lpush2_%=\n\t"
-#define PLK_ASM_PUSH_BODY4                                                            \
-    PLK_ASM_PUSH(0, 0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_PUSH(1, 8, 9, 10, 11, 12, 13, 14, 15)     \
-    PLK_ASM_PUSH(2, 16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_PUSH(3, 24, 25, 26, 27, 28, 29, 30, 31)
+/* Dispatch: every handler starts at a 256-byte boundary, in the order of its 5-bit handler index (the low bits of the
+ * op word), so the address of the handler is base + (index << 8): an op costs s_swappc into the handler and s_setpc
+ * back -- no dispatcher with its compare-and-branch chain (one more taken branch per op, up to five compares for a
+ * stack op), and PUSH / POPMUL have one handler per stack slot instead of a second chain. */
+#define PLK_H_ALIGN ".p2align 8\n"
+#define PLK_ASM_CALL(SREG)                                                            \
+    "s_and_b32 s97, " #SREG ", 31\n\t"                                                \
+    "s_lshl_b32 s97, s97, 8\n\t"                                                      \
+    "s_add_u32 s98, s90, s97\n\t"                                                     \
+    "s_addc_u32 s99, s91, 0\n\t"                                                      \
+    "s_mov_b32 s96, " #SREG "\n\t"                                                    \
+    "s_swappc_b64 s[88:89], s[98:99]\n\t"
+#define PLK_H_UNUSED PLK_H_ALIGN "s_setpc_b64 s[88:89]\n"
 
 /* D <= 4: the stack lives in ordinary VGPRs v[54:85] (slot d = v[54 + 8d : 61 + 8d]).  A waiting vector is then an
  * operand of the multiply that pops it: PUSH = 4 moves, POPMUL = 4 multiplies, against 8 + 8 accumulation-register
  * moves + 4 multiplies with the AGPR stack -- 12 of 20 vector instructions per push / pop pair, ~12 % of all vector
  * instructions of the kernel at BASELINE config 3 (the kernel is bound by vector issue, not by registers: 88 VGPRs
  * still give 5 waves per SIMD). */
-#define PLK_ASM_VPOP(D_, A0, A1, B0, B1, C0, C1, E0, E1)                                  \
-    ".Lpop" #D_ "_%=:\n\t"                                                                \
+#define PLK_ASM_VPOP(A0, A1, B0, B1, C0, C1, E0, E1)                                      \
+    PLK_H_ALIGN                                                                           \
     "v_mul_f64 v[24:25], v[24:25], v[" #A0 ":" #A1 "]\n\t"                                \
     "v_mul_f64 v[26:27], v[26:27], v[" #B0 ":" #B1 "]\n\t"                                \
     "v_mul_f64 v[28:29], v[28:29], v[" #C0 ":" #C1 "]\n\t"                                \
     "v_mul_f64 v[30:31], v[30:31], v[" #E0 ":" #E1 "]\n\t"                                \
     "s_setpc_b64 s[88:89]\n"
-#define PLK_ASM_VPUSH(D_, A0, A1, B0, B1, C0, C1, E0, E1)                                 \
-    ".Lpush" #D_ "_%=:\n\t"                                                               \
+#define PLK_ASM_VPUSH(A0, A1, B0, B1, C0, C1, E0, E1)                                     \
+    PLK_H_ALIGN                                                                           \
     "v_mov_b64 v[" #A0 ":" #A1 "], v[24:25]\n\t"                                          \
     "v_mov_b64 v[" #B0 ":" #B1 "], v[26:27]\n\t"                                          \
     "v_mov_b64 v[" #C0 ":" #C1 "], v[28:29]\n\t"                                          \
     "v_mov_b64 v[" #E0 ":" #E1 "], v[30:31]\n\t"                                          \
     "s_setpc_b64 s[88:89]\n"
-#define PLK_ASM_SLOTS_D4_POP  PLK_ASM_POP_CHAIN4 "s_branch .Lpop3_%=\n"                                   \
-    PLK_ASM_VPOP(0, 54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPOP(1, 62, 63, 64, 65, 66, 67, 68, 69)         \
-    PLK_ASM_VPOP(2, 70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPOP(3, 78, 79, 80, 81, 82, 83, 84, 85)
-#define PLK_ASM_SLOTS_D4_PUSH PLK_ASM_PUSH_CHAIN4 "s_branch .Lpush3_%=\n"                                 \
-    PLK_ASM_VPUSH(0, 54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPUSH(1, 62, 63, 64, 65, 66, 67, 68, 69)       \
-    PLK_ASM_VPUSH(2, 70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPUSH(3, 78, 79, 80, 81, 82, 83, 84, 85)
+/* handler indices 8..15 (PUSH slot 0..7) and 16..23 (POPMUL slot 0..7) */
+#define PLK_ASM_SLOTS_D4_PUSH                                                                             \
+    PLK_ASM_VPUSH(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPUSH(62, 63, 64, 65, 66, 67, 68, 69)             \
+    PLK_ASM_VPUSH(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPUSH(78, 79, 80, 81, 82, 83, 84, 85)             \
+    PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED
+#define PLK_ASM_SLOTS_D4_POP                                                                              \
+    PLK_ASM_VPOP(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPOP(62, 63, 64, 65, 66, 67, 68, 69)               \
+    PLK_ASM_VPOP(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPOP(78, 79, 80, 81, 82, 83, 84, 85)               \
+    PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED
 #define PLK_CLOBBER_V54_85 "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", \
     "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85"
-#define PLK_ASM_SLOTS_D8_POP                                                          \
-    PLK_ASM_POP_CHAIN4                                                                \
-    "s_cmp_eq_u32 s97, 3\n\ts_cbranch_scc1 .Lpop3_%=\n\t"                             \
-    "s_cmp_eq_u32 s97, 4\n\ts_cbranch_scc1 .Lpop4_%=\n\t"                             \
-    "s_cmp_eq_u32 s97, 5\n\ts_cbranch_scc1 .Lpop5_%=\n\t"                             \
-    "s_cmp_eq_u32 s97, 6\n\ts_cbranch_scc1 .Lpop6_%=\n\t"                             \
-    "s_branch .Lpop7_%=\n"                                                            \
-    PLK_ASM_POP_BODY4                                                                 \
-    PLK_ASM_POP(4, 32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_POP(5, 40, 41, 42, 43, 44, 45, 46, 47) \
-    PLK_ASM_POP(6, 48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_POP(7, 56, 57, 58, 59, 60, 61, 62, 63)
+
+/* D = 8: the stack lives in the accumulation registers a[0:63], moved through v[32:39] */
+#define PLK_ASM_POP(R0, R1, R2, R3, R4, R5, R6, R7)                                  \
+    PLK_H_ALIGN                                                                      \
+    "v_accvgpr_read_b32 v32, a" #R0 "\n\tv_accvgpr_read_b32 v33, a" #R1 "\n\t"       \
+    "v_accvgpr_read_b32 v34, a" #R2 "\n\tv_accvgpr_read_b32 v35, a" #R3 "\n\t"       \
+    "v_accvgpr_read_b32 v36, a" #R4 "\n\tv_accvgpr_read_b32 v37, a" #R5 "\n\t"       \
+    "v_accvgpr_read_b32 v38, a" #R6 "\n\tv_accvgpr_read_b32 v39, a" #R7 "\n\t"       \
+    "v_mul_f64 v[24:25], v[24:25], v[32:33]\n\t"                                     \
+    "v_mul_f64 v[26:27], v[26:27], v[34:35]\n\t"                                     \
+    "v_mul_f64 v[28:29], v[28:29], v[36:37]\n\t"                                     \
+    "v_mul_f64 v[30:31], v[30:31], v[38:39]\n\t"                                     \
+    "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_PUSH(R0, R1, R2, R3, R4, R5, R6, R7)                                 \
+    PLK_H_ALIGN                                                                      \
+    "v_accvgpr_write_b32 a" #R0 ", v24\n\tv_accvgpr_write_b32 a" #R1 ", v25\n\t"     \
+    "v_accvgpr_write_b32 a" #R2 ", v26\n\tv_accvgpr_write_b32 a" #R3 ", v27\n\t"     \
+    "v_accvgpr_write_b32 a" #R4 ", v28\n\tv_accvgpr_write_b32 a" #R5 ", v29\n\t"     \
+    "v_accvgpr_write_b32 a" #R6 ", v30\n\tv_accvgpr_write_b32 a" #R7 ", v31\n\t"     \
+    "s_setpc_b64 s[88:89]\n"
 #define PLK_ASM_SLOTS_D8_PUSH                                                         \
-    PLK_ASM_PUSH_CHAIN4                                                               \
-    "s_cmp_eq_u32 s97, 3\n\ts_cbranch_scc1 .Lpush3_%=\n\t"                            \
-    "s_cmp_eq_u32 s97, 4\n\ts_cbranch_scc1 .Lpush4_%=\n\t"                            \
-    "s_cmp_eq_u32 s97, 5\n\ts_cbranch_scc1 .Lpush5_%=\n\t"                            \
-    "s_cmp_eq_u32 s97, 6\n\ts_cbranch_scc1 .Lpush6_%=\n\t"                            \
-    "s_branch .Lpush7_%=\n"                                                           \
-    PLK_ASM_PUSH_BODY4                                                                \
-    PLK_ASM_PUSH(4, 32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_PUSH(5, 40, 41, 42, 43, 44, 45, 46, 47) \
-    PLK_ASM_PUSH(6, 48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_PUSH(7, 56, 57, 58, 59, 60, 61, 62, 63)
+    PLK_ASM_PUSH(0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_PUSH(8, 9, 10, 11, 12, 13, 14, 15)           \
+    PLK_ASM_PUSH(16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_PUSH(24, 25, 26, 27, 28, 29, 30, 31) \
+    PLK_ASM_PUSH(32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_PUSH(40, 41, 42, 43, 44, 45, 46, 47) \
+    PLK_ASM_PUSH(48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_PUSH(56, 57, 58, 59, 60, 61, 62, 63)
+#define PLK_ASM_SLOTS_D8_POP                                                          \
+    PLK_ASM_POP(0, 1, 2, 3, 4, 5, 6, 7) PLK_ASM_POP(8, 9, 10, 11, 12, 13, 14, 15)             \
+    PLK_ASM_POP(16, 17, 18, 19, 20, 21, 22, 23) PLK_ASM_POP(24, 25, 26, 27, 28, 29, 30, 31)   \
+    PLK_ASM_POP(32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_POP(40, 41, 42, 43, 44, 45, 46, 47)   \
+    PLK_ASM_POP(48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_POP(56, 57, 58, 59, 60, 61, 62, 63)
+
+/* the tail of an observation handler: request the value of the next observation op and the code of the one after */
+#define PLK_ASM_TIPNEXT                                                               \
+        "s_bfe_u32 s98, s96, 0xb0005\n\t"                                             \
+        "s_mul_i32 s98, s98, s93\n\t"                                                 \
+        "s_add_u32 s98, s98, s92\n\t"                                                 \
+        "s_lshr_b32 s99, s96, 16\n\t"                                                 \
+        "s_mul_i32 s99, s99, s94\n\t"                                                 \
+        "v_bfe_u32 v43, v41, v45, s35\n\t"                                           \
+        "v_lshl_add_u32 v40, v43, 5, s98\n\t"                                         \
+        "ds_read_b64 v[46:47], v40\n\t"                                               \
+        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
+        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
+        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
+        "v_add_u32 v43, s99, v44\n\t"                                                 \
+        "ds_read_u8 v41, v43\n\t"                                                     \
+        "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_TIPMUL                                                                \
+        "v_mul_f64 v[24:25], v[24:25], v[46:47]\n\t"                                  \
+        "v_mul_f64 v[26:27], v[26:27], v[48:49]\n\t"                                  \
+        "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
+        "v_mul_f64 v[30:31], v[30:31], v[52:53]\n\t"
 
 #define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS)                                        \
         /* ---- prologue: operands into the fixed registers ---- */                   \
@@ -150,7 +166,7 @@
         "ds_read_u8 v41, %[secaddr]\n\t"                                              \
         "s_getpc_b64 s[90:91]\n"                                                      \
         ".Lpcref_%=:\n\t"                                                             \
-        "s_add_u32 s90, s90, .Ldispatch_%=-.Lpcref_%=\n\t"                            \
+        "s_add_u32 s90, s90, .Lh0_%=-.Lpcref_%=\n\t"                                  \
         "s_addc_u32 s91, s91, 0\n\t"                                                  \
         "s_waitcnt lgkmcnt(0)\n"                                                      \
         /* ---- one block of 8 ops per iteration; the next block is already in flight ---- */ \
@@ -166,24 +182,22 @@
         "s_mov_b64 s[72:73], s[80:81]\n\t"                                            \
         "s_mov_b64 s[74:75], s[82:83]\n\t"                                            \
         "s_branch .Lblock_%=\n"                                                       \
-        /* ---- dispatcher: s96 = op word ---- */                                     \
-        ".Ldispatch_%=:\n\t"                                                          \
-        "s_and_b32 s97, s96, 7\n\t"                                                   \
-        "s_cmp_eq_u32 s97, 2\n\t"                                                     \
-        "s_cbranch_scc1 .Lmatvec_%=\n\t"                                              \
-        "s_cmp_eq_u32 s97, 5\n\t"                                                     \
-        "s_cbranch_scc1 .Ltipmul_nw_%=\n\t"                                           \
-        "s_cmp_lt_u32 s97, 2\n\t"                                                     \
-        "s_cbranch_scc1 .Ltip_%=\n\t"                                                 \
-        "s_cmp_eq_u32 s97, 4\n\t"                                                     \
-        "s_cbranch_scc1 .Lpop_%=\n\t"                                                 \
-        "s_cmp_eq_u32 s97, 3\n\t"                                                     \
-        "s_cbranch_scc1 .Lpush_%=\n\t"                                                \
-        "s_cmp_eq_u32 s97, 6\n\t"                                                     \
-        "s_cbranch_scc1 .Lscale_%=\n\t"                                               \
-        "s_branch .Ldone_%=\n"                                                        \
-        /* ---- MATVEC: x = M x in place ---- */                                      \
-        ".Lmatvec_%=:\n\t"                                                            \
+        /* ==== handlers, 256 bytes apart, in handler-index order; s96 = op word ==== */ \
+        /* ---- 0 TIP_SET, 1 TIP_MUL: consume the prefetched value, start the next fetches ---- */ \
+        PLK_H_ALIGN                                                                   \
+        ".Lh0_%=:\n\t"                                                                \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "v_mov_b64 v[24:25], v[46:47]\n\t"                                            \
+        "v_mov_b64 v[26:27], v[48:49]\n\t"                                            \
+        "v_mov_b64 v[28:29], v[50:51]\n\t"                                            \
+        "v_mov_b64 v[30:31], v[52:53]\n\t"                                            \
+        PLK_ASM_TIPNEXT                                                               \
+        PLK_H_ALIGN                                                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        PLK_ASM_TIPMUL                                                                \
+        PLK_ASM_TIPNEXT                                                               \
+        /* ---- 2 MATVEC: x = M x in place ---- */                                    \
+        PLK_H_ALIGN                                                                   \
         "s_waitcnt lgkmcnt(0)\n\t"                                                    \
         "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
         "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
@@ -206,56 +220,15 @@
         "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
         "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
         "s_setpc_b64 s[88:89]\n"                                                      \
-        /* ---- TIP_SET / TIP_MUL: consume the prefetched value, start the next fetches ---- */ \
-        ".Ltip_%=:\n\t"                                                               \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
-        "s_cmp_eq_u32 s97, 0\n\t"                                                     \
-        "s_cbranch_scc1 .Ltipset_%=\n"                                                \
-        /* opcode 5 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which   \
-         * starts with a full wait) ran since the value was requested, so no wait is needed here \
-         * and the matrix load that MATVEC left in flight stays in flight */           \
-        ".Ltipmul_nw_%=:\n\t"                                                         \
-        "v_mul_f64 v[24:25], v[24:25], v[46:47]\n\t"                                  \
-        "v_mul_f64 v[26:27], v[26:27], v[48:49]\n\t"                                  \
-        "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
-        "v_mul_f64 v[30:31], v[30:31], v[52:53]\n\t"                                  \
-        "s_branch .Ltipnext_%=\n"                                                     \
-        ".Ltipset_%=:\n\t"                                                            \
-        "v_mov_b64 v[24:25], v[46:47]\n\t"                                            \
-        "v_mov_b64 v[26:27], v[48:49]\n\t"                                            \
-        "v_mov_b64 v[28:29], v[50:51]\n\t"                                            \
-        "v_mov_b64 v[30:31], v[52:53]\n"                                              \
-        ".Ltipnext_%=:\n\t"                                                           \
-        "s_bfe_u32 s98, s96, 0xd0003\n\t"                                             \
-        "s_mul_i32 s98, s98, s93\n\t"                                                 \
-        "s_add_u32 s98, s98, s92\n\t"                                                 \
-        "s_lshr_b32 s99, s96, 16\n\t"                                                 \
-        "s_mul_i32 s99, s99, s94\n\t"                                                 \
-        "v_bfe_u32 v43, v41, v45, s35\n\t"                                           \
-        "v_lshl_add_u32 v40, v43, 5, s98\n\t"                                         \
-        "ds_read_b64 v[46:47], v40\n\t"                                               \
-        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
-        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
-        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
-        "v_add_u32 v43, s99, v44\n\t"                                                 \
-        "ds_read_u8 v41, v43\n\t"                                                     \
-        "s_setpc_b64 s[88:89]\n"                                                      \
-        /* ---- POPMUL d ---- */                                                      \
-        ".Lpop_%=:\n\t"                                                               \
-        "s_bfe_u32 s97, s96, 0xd0003\n\t"                                             \
-        POP_SLOTS                                                                     \
-        ".Lpopmul_%=:\n\t"                                                            \
-        "v_mul_f64 v[24:25], v[24:25], v[32:33]\n\t"                                  \
-        "v_mul_f64 v[26:27], v[26:27], v[34:35]\n\t"                                  \
-        "v_mul_f64 v[28:29], v[28:29], v[36:37]\n\t"                                  \
-        "v_mul_f64 v[30:31], v[30:31], v[38:39]\n\t"                                  \
-        "s_setpc_b64 s[88:89]\n"                                                      \
-        /* ---- PUSH d ---- */                                                        \
-        ".Lpush_%=:\n\t"                                                              \
-        "s_bfe_u32 s97, s96, 0xd0003\n\t"                                             \
-        PUSH_SLOTS                                                                    \
-        /* ---- SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */ \
-        ".Lscale_%=:\n\t"                                                             \
+        PLK_H_UNUSED PLK_H_UNUSED                                                     \
+        /* ---- 5 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which starts with a full \
+         * wait) ran since the value was requested, so no wait is needed here and the matrix load that MATVEC   \
+         * left in flight stays in flight ---- */                                     \
+        PLK_H_ALIGN                                                                   \
+        PLK_ASM_TIPMUL                                                                \
+        PLK_ASM_TIPNEXT                                                               \
+        /* ---- 6 SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */ \
+        PLK_H_ALIGN                                                                   \
         "v_max_u32 v43, v25, v27\n\t"                                                 \
         "v_max3_u32 v43, v29, v31, v43\n\t"                                           \
         "v_lshrrev_b32 v43, 20, v43\n\t"                                              \
@@ -266,7 +239,14 @@
         "v_ldexp_f64 v[30:31], v[30:31], v40\n\t"                                     \
         "v_add3_u32 v42, v42, v43, s95\n\t"                                           \
         "s_setpc_b64 s[88:89]\n"                                                      \
+        /* ---- 7 END ---- */                                                         \
+        PLK_H_ALIGN                                                                   \
+        "s_branch .Ldone_%=\n"                                                        \
+        /* ---- 8..15 PUSH slot d, 16..23 POPMUL slot d ---- */                       \
+        PUSH_SLOTS                                                                    \
+        POP_SLOTS                                                                     \
         /* ---- epilogue ---- */                                                      \
+        PLK_H_ALIGN                                                                   \
         ".Ldone_%=:\n\t"                                                              \
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                           \
         "v_mov_b32 %[x0lo], v24\n\tv_mov_b32 %[x0hi], v25\n\t"                        \

@@ -215,10 +215,10 @@ struct PlkFused {
     bool asm_ok = false;               /* the assembly interpreter's field widths and stack depth suffice */
 };
 
-/* the assembly interpreter's op-word fields: 8 stack slots, 13 bits of tip slot, 16 bits of staged row */
+/* the assembly interpreter's op-word fields: 8 stack slots, 11 bits of tip slot, 16 bits of staged row */
 static inline bool plk_fused_asm_ok(const PlkProgram &pg)
 {
-    return pg.slots_needed <= 8 && pg.tip_edge.size() + 1 < 8192 && pg.obs_nodes.size() < 65536;
+    return pg.slots_needed <= 8 && pg.tip_edge.size() + 1 < 2048 && pg.obs_nodes.size() < 65536;
 }
 
 static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
@@ -241,8 +241,9 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
     fu.first_row = next_row;
     for (int pc = 0; pc < nops; pc++)
         if ((fu.fops[pc].x & 0xff) == OP_MATVEC) { fu.fops[pc].w = (int)fu.mat_edge.size(); fu.mat_edge.push_back(pg.op_edge[pc]); }
-    /* assembly interpreter: 32-bit words {opcode | y<<3 | z<<16} in blocks of 8; an observation op carries the tip
-     * slot of the NEXT observation op (y) and the code row of the one after next (z): the prefetch chain of
+    /* assembly interpreter: 32-bit words {handler index | y<<5 | z<<16} in blocks of 8 (handler index = opcode, or
+     * 8 + slot for PUSH, 16 + slot for POPMUL: the interpreter jumps to base + 256 * index); an observation op carries
+     * the tip slot of the NEXT observation op (y) and the code row of the one after next (z): the prefetch chain of
      * plk_fused4_asm.h.  An internal node's own data is an observation on the pseudo tip slot ntips. */
     const int ntips = (int)pg.tip_edge.size();
     std::vector<int> obs_t, obs_row;
@@ -264,11 +265,11 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
             const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
             const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
                                                    : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
-            wv = oc | (tn << 3) | (rn << 16);
+            wv = oc | (tn << 5) | (rn << 16);
             matvec_since_obs = false;
             oi++;
         } else if (code == OP_PUSH || code == OP_POPMUL) {
-            wv |= (unsigned)fu.fops[pc].y << 3;
+            wv = (code == OP_PUSH ? 8u : 16u) + (unsigned)fu.fops[pc].y;
         }
         fu.words[pc] = wv;
     }
@@ -336,7 +337,11 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
         /* s_load_dwordx8 of block b + 1 is issued here: in range by the test above */
         for (int i = 0; i < 8; i++) {
             const unsigned w = fu.words[b * 8 + i];
-            const unsigned oc = w & 7, y = (w >> 3) & 0x1fff, z = w >> 16;
+            /* the kernel jumps to handler (w & 31): 0..7 = opcode, 8 + d = PUSH slot d, 16 + d = POPMUL slot d */
+            const unsigned hidx = w & 31, z = w >> 16;
+            if (hidx >= 24 || hidx == 3 || hidx == 4) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)(b * 8 + i));
+            const unsigned oc = hidx >= 16 ? (unsigned)OP_POPMUL : hidx >= 8 ? (unsigned)OP_PUSH : hidx;
+            const unsigned y = hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
             const size_t pc = b * 8 + i;
             if (oc == OP_END) {
                 if ((int)pc != nops) return plk_fmt("asm program: END at word %ld, program has %ld ops", (long)pc, nops);
