@@ -11,7 +11,7 @@
  *
  * Program format (built by prepare_stream_asm in plk_engine.hip): 32-bit op words in
  * blocks of 8, fetched a whole block ahead with one s_load_dwordx8;
- *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 5 TIP_MUL without wait, 6 SCALE, 7 END, 8 + d PUSH to
+ *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 MATVEC + TIP_MUL in one word, 5 TIP_MUL without wait, 6 SCALE, 7 END, 8 + d PUSH to
  *   stack slot d, 16 + d POPMUL of slot d), bits 15:5 field y, bits 31:16 field z
  *   MATVEC            x = P x; matrices are consumed in stream order, the next one is
  *                     requested as soon as the current one has been used
@@ -48,8 +48,7 @@
 #define PLK_ASM_CALL(SREG)                                                            \
     "s_and_b32 s97, " #SREG ", 31\n\t"                                                \
     "s_lshl_b32 s97, s97, 8\n\t"                                                      \
-    "s_add_u32 s98, s90, s97\n\t"                                                     \
-    "s_addc_u32 s99, s91, 0\n\t"                                                      \
+    "s_or_b32 s98, s90, s97\n\t"          /* handler 0 sits on an 8 KB boundary; s99 = high half, set once */ \
     "s_mov_b32 s96, " #SREG "\n\t"                                                    \
     "s_swappc_b64 s[88:89], s[98:99]\n\t"
 #define PLK_H_UNUSED PLK_H_ALIGN "s_setpc_b64 s[88:89]\n"
@@ -120,15 +119,15 @@
         "s_bfe_u32 s98, s96, 0xb0005\n\t"                                             \
         "s_mul_i32 s98, s98, s93\n\t"                                                 \
         "s_add_u32 s98, s98, s92\n\t"                                                 \
-        "s_lshr_b32 s99, s96, 16\n\t"                                                 \
-        "s_mul_i32 s99, s99, s94\n\t"                                                 \
+        "s_lshr_b32 s97, s96, 16\n\t"                                                 \
+        "s_mul_i32 s97, s97, s94\n\t"                                                 \
         "v_bfe_u32 v43, v41, v45, s35\n\t"                                           \
         "v_lshl_add_u32 v40, v43, 5, s98\n\t"                                         \
         "ds_read_b64 v[46:47], v40\n\t"                                               \
         "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
         "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
         "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
-        "v_add_u32 v43, s99, v44\n\t"                                                 \
+        "v_add_u32 v43, s97, v44\n\t"                                                 \
         "ds_read_u8 v41, v43\n\t"                                                     \
         "s_setpc_b64 s[88:89]\n"
 #define PLK_ASM_TIPMUL                                                                \
@@ -168,6 +167,7 @@
         ".Lpcref_%=:\n\t"                                                             \
         "s_add_u32 s90, s90, .Lh0_%=-.Lpcref_%=\n\t"                                  \
         "s_addc_u32 s91, s91, 0\n\t"                                                  \
+        "s_mov_b32 s99, s91\n\t"                                                      \
         "s_waitcnt lgkmcnt(0)\n"                                                      \
         /* ---- one block of 8 ops per iteration; the next block is already in flight ---- */ \
         ".Lblock_%=:\n\t"                                                             \
@@ -184,7 +184,7 @@
         "s_branch .Lblock_%=\n"                                                       \
         /* ==== handlers, 256 bytes apart, in handler-index order; s96 = op word ==== */ \
         /* ---- 0 TIP_SET, 1 TIP_MUL: consume the prefetched value, start the next fetches ---- */ \
-        PLK_H_ALIGN                                                                   \
+        ".p2align 13\n"                                                               \
         ".Lh0_%=:\n\t"                                                                \
         "s_waitcnt lgkmcnt(0)\n\t"                                                    \
         "v_mov_b64 v[24:25], v[46:47]\n\t"                                            \
@@ -220,7 +220,33 @@
         "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
         "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
         "s_setpc_b64 s[88:89]\n"                                                      \
-        PLK_H_UNUSED PLK_H_UNUSED                                                     \
+        /* ---- 3 (+ the space of 4) MATVEC followed by TIP_MUL: one op word, one dispatch.  The product's wait covers
+         * the prefetched tip value, and the word carries the observation's fields ---- */ \
+        PLK_H_ALIGN                                                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
+        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
+        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
+        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"                        \
+        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
+        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
+        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
+        "s_add_u32 s86, s86, 0x80\n\t"                                                \
+        "s_addc_u32 s87, s87, 0\n\t"                                                  \
+        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
+        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
+        PLK_ASM_TIPMUL                                                                \
+        PLK_ASM_TIPNEXT                                                               \
+        /* (the pair handler is between 256 and 512 bytes long, so the next 256-byte boundary is handler 5's) */ \
         /* ---- 5 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which starts with a full \
          * wait) ran since the value was requested, so no wait is needed here and the matrix load that MATVEC   \
          * left in flight stays in flight ---- */                                     \

@@ -32,6 +32,7 @@ enum {
 };
 /* opcode 5 of the assembly interpreter's word format: TIP_MUL that may skip its wait (plk_fused4_asm.h) */
 #define PLK_WORD_TIPMUL_NOWAIT 5u
+#define PLK_WORD_MATVEC_TIPMUL 3u      /* assembly interpreter: MATVEC and the TIP_MUL that follows it, as one op word */
 
 struct plk_op2 { int x, y; };          /* layout of HIP's int2: x = opcode | tip_slot << 8, y = node / stack slot */
 struct plk_op4 { int x, y, z, w; };    /* layout of HIP's int4 */
@@ -254,24 +255,39 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
     }
     const int nwords = ((nops + 1 + 7) / 8) * 8 + 8;
     fu.words.assign(nwords, (unsigned)OP_END);
-    size_t oi = 0;
+    size_t oi = 0, nw = 0;
     bool matvec_since_obs = false;   /* a MATVEC (full wait) ran since the last observation op */
     for (int pc = 0; pc < nops; pc++) {
         const int code = fu.fops[pc].x & 0xff;
         unsigned wv = (unsigned)code;
-        if (code == OP_MATVEC) matvec_since_obs = true;
-        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+        auto obs_fields = [&]() {
             const unsigned tn = oi + 1 < obs_t.size() ? (unsigned)obs_t[oi + 1] : 0u;
             const unsigned rn = oi + 2 < obs_row.size() ? (unsigned)obs_row[oi + 2] : 0u;
+            return (tn << 5) | (rn << 16);
+        };
+        if (code == OP_MATVEC) {
+            const int nx = pc + 1 < nops ? (fu.fops[pc + 1].x & 0xff) : OP_END;
+            if ((nx == OP_TIP_MUL || nx == OP_NODE_MUL) && oi > 0) {
+                /* MATVEC followed by TIP_MUL (an internal child, then a leaf child or the node's own data): one word,
+                 * handler 3; the product's wait covers the prefetched tip value */
+                fu.words[nw++] = PLK_WORD_MATVEC_TIPMUL | obs_fields();
+                oi++;
+                matvec_since_obs = false;
+                pc++;
+                continue;
+            }
+            matvec_since_obs = true;
+        }
+        if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
             const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
                                                    : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
-            wv = oc | (tn << 5) | (rn << 16);
+            wv = oc | obs_fields();
             matvec_since_obs = false;
             oi++;
         } else if (code == OP_PUSH || code == OP_POPMUL) {
             wv = (code == OP_PUSH ? 8u : 16u) + (unsigned)fu.fops[pc].y;
         }
-        fu.words[pc] = wv;
+        fu.words[nw++] = wv;
     }
     fu.asm_first_tip = obs_t.empty() ? 0 : obs_t[0];
     fu.asm_first_row = obs_row.empty() ? 0 : obs_row[0];
@@ -332,59 +348,61 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
     bool waited = true;               /* lgkmcnt(0) seen since the in-flight value was requested (prologue waits) */
     std::vector<char> full(D, 0);
     const size_t nblocks = fu.words.size() / 8;
+    size_t pc = 0;                    /* op of the program the next word stands for (a pair word stands for two) */
+    /* one observation op of the chain: the word's fields name the next observation's slot and the row after next */
+    auto observation = [&](size_t wi, unsigned y, unsigned z, bool is_set, bool no_wait) -> std::string {
+        if ((int)pc >= nops) return "asm program: op beyond the program";
+        const int code = pg.ops[pc].x & 0xff;
+        if (code != OP_TIP_SET && code != OP_TIP_MUL && code != OP_NODE_MUL) return plk_fmt("asm program: word %ld is not an observation op", (long)wi);
+        if (is_set != (code == OP_TIP_SET)) return plk_fmt("asm program: word %ld: SET/MUL mismatch", (long)wi);
+        if (no_wait && !waited) return plk_fmt("asm program: word %ld skips a wait it needs", (long)wi);
+        if (oi >= slot.size() || cur_tip != slot[oi] || cur_row != rowv[oi]) return plk_fmt("asm program: prefetch chain delivers the wrong observation at word %ld", (long)wi);
+        if (!tip_ok(y) || !row_ok(z)) return plk_fmt("asm program: word %ld prefetches out of range (slot %ld, row %ld)", (long)wi, y, z);
+        cur_tip = y; cur_row = next_row; next_row = z;
+        if (oi + 1 < slot.size() && (cur_tip != slot[oi + 1] || cur_row != rowv[oi + 1])) return plk_fmt("asm program: chain after word %ld", (long)wi);
+        oi++;
+        waited = false;
+        pc++;
+        return "";
+    };
+    auto product = [&](size_t wi) -> std::string {
+        if ((int)pc >= nops) return "asm program: op beyond the program";
+        if ((pg.ops[pc].x & 0xff) != OP_MATVEC) return plk_fmt("asm program: word %ld is not the program's op", (long)wi);
+        if (mi >= nmat || fu.mat_edge[mi] != pg.op_edge[pc]) return plk_fmt("asm program: matrix %ld is not the op's edge", mi);
+        mi++;                                   /* loads matrix mi (<= nmat: the spare) */
+        waited = true;
+        pc++;
+        return "";
+    };
     for (size_t b = 0;; b++) {
         if (b + 1 >= nblocks) return "asm program: ran past the spare block (no END)";
         /* s_load_dwordx8 of block b + 1 is issued here: in range by the test above */
         for (int i = 0; i < 8; i++) {
-            const unsigned w = fu.words[b * 8 + i];
-            /* the kernel jumps to handler (w & 31): 0..7 = opcode, 8 + d = PUSH slot d, 16 + d = POPMUL slot d */
+            const size_t wi = b * 8 + i;
+            const unsigned w = fu.words[wi];
+            /* the kernel jumps to handler (w & 31): 0..7 = opcode (3 = MATVEC + TIP_MUL, occupying the slots of 3 and 4),
+             * 8 + d = PUSH slot d, 16 + d = POPMUL slot d */
             const unsigned hidx = w & 31, z = w >> 16;
-            if (hidx >= 24 || hidx == 3 || hidx == 4) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)(b * 8 + i));
-            const unsigned oc = hidx >= 16 ? (unsigned)OP_POPMUL : hidx >= 8 ? (unsigned)OP_PUSH : hidx;
+            if (hidx >= 24 || hidx == 4) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)wi);
             const unsigned y = hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
-            const size_t pc = b * 8 + i;
-            if (oc == OP_END) {
-                if ((int)pc != nops) return plk_fmt("asm program: END at word %ld, program has %ld ops", (long)pc, nops);
+            std::string bad;
+            if (hidx == OP_END) {
+                if ((int)pc != nops) return plk_fmt("asm program: END at word %ld after %ld of the program's ops", (long)wi, (long)pc);
                 if (oi != slot.size()) return "asm program: observation ops missing";
                 if (mi != nmat) return "asm program: matrix stream not consumed";
                 return "";
+            } else if (hidx == OP_MATVEC) bad = product(wi);
+            else if (hidx == PLK_WORD_MATVEC_TIPMUL) { bad = product(wi); if (bad.empty()) bad = observation(wi, y, z, false, true); }
+            else if (hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT) bad = observation(wi, y, z, hidx == OP_TIP_SET, hidx == PLK_WORD_TIPMUL_NOWAIT);
+            else if (hidx == OP_SCALE) { if ((int)pc >= nops || (pg.ops[pc].x & 0xff) != OP_SCALE) bad = plk_fmt("asm program: word %ld is not the program's op", (long)wi); pc++; }
+            else {
+                const bool push = hidx < 16;
+                if ((int)pc >= nops || (pg.ops[pc].x & 0xff) != (push ? OP_PUSH : OP_POPMUL) || (int)y >= D || (int)y != pg.ops[pc].y || (full[y] != 0) == push)
+                    bad = plk_fmt(push ? "asm program: bad PUSH at word %ld" : "asm program: bad POPMUL at word %ld", (long)wi);
+                else full[y] = push;
+                pc++;
             }
-            if ((int)pc >= nops) return "asm program: op beyond the program";
-            const int code = pg.ops[pc].x & 0xff;
-            switch (oc) {
-            case OP_MATVEC:
-                if (code != OP_MATVEC) return plk_fmt("asm program: word %ld is not the program's op", (long)pc);
-                if (fu.mat_edge[mi] != pg.op_edge[pc]) return plk_fmt("asm program: matrix %ld is not the op's edge", mi);
-                mi++;                                   /* loads matrix mi (<= nmat: the spare) */
-                if (mi > nmat) return "asm program: matrix stream overrun";
-                waited = true;
-                break;
-            case OP_TIP_SET: case OP_TIP_MUL: case PLK_WORD_TIPMUL_NOWAIT: {
-                if (code != OP_TIP_SET && code != OP_TIP_MUL && code != OP_NODE_MUL) return plk_fmt("asm program: word %ld is not an observation op", (long)pc);
-                if ((oc == OP_TIP_SET) != (code == OP_TIP_SET)) return plk_fmt("asm program: word %ld: SET/MUL mismatch", (long)pc);
-                if (oc == PLK_WORD_TIPMUL_NOWAIT && !waited) return plk_fmt("asm program: word %ld skips a wait it needs", (long)pc);
-                if (oi >= slot.size() || cur_tip != slot[oi] || cur_row != rowv[oi]) return plk_fmt("asm program: prefetch chain delivers the wrong observation at word %ld", (long)pc);
-                if (!tip_ok(y) || !row_ok(z)) return plk_fmt("asm program: word %ld prefetches out of range (slot %ld, row %ld)", (long)pc, y, z);
-                cur_tip = y; cur_row = next_row; next_row = z;
-                if (oi + 1 < slot.size() && (cur_tip != slot[oi + 1] || cur_row != rowv[oi + 1])) return plk_fmt("asm program: chain after word %ld", (long)pc);
-                oi++;
-                waited = false;
-                break;
-            }
-            case OP_PUSH:
-                if (code != OP_PUSH || (int)y >= D || (int)y != pg.ops[pc].y || full[y]) return plk_fmt("asm program: bad PUSH at word %ld", (long)pc);
-                full[y] = 1;
-                break;
-            case OP_POPMUL:
-                if (code != OP_POPMUL || (int)y >= D || (int)y != pg.ops[pc].y || !full[y]) return plk_fmt("asm program: bad POPMUL at word %ld", (long)pc);
-                full[y] = 0;
-                break;
-            case OP_SCALE:
-                if (code != OP_SCALE) return plk_fmt("asm program: word %ld is not the program's op", (long)pc);
-                break;
-            default:
-                return plk_fmt("asm program: unknown opcode in word %ld", (long)pc);
-            }
+            if (!bad.empty()) return bad;
         }
         waited = true;                /* s_waitcnt lgkmcnt(0) at the end of every block */
     }

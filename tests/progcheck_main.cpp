@@ -161,10 +161,11 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
             PlkFused f2 = fu;
             bool touched = false;
             for (size_t w = 0; w < f2.words.size() && !touched; w++)
-                if ((f2.words[w] & 7) <= 1) { f2.words[w] = (f2.words[w] & 0xffff) | ((unsigned)pg.obs_nodes.size() << 16); touched = true; }
+                if ((f2.words[w] & 31) <= 1) { f2.words[w] = (f2.words[w] & 0xffff) | ((unsigned)pg.obs_nodes.size() << 16); touched = true; }
             if (touched && plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: row field out of range accepted";
             f2 = fu;
-            f2.words[pg.ops.size()] = OP_SCALE;      /* END overwritten */
+            for (size_t w = 0; w < f2.words.size(); w++)
+                if ((f2.words[w] & 31) == OP_END) { f2.words[w] = OP_SCALE; break; }      /* the first END overwritten */
             if (plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: missing END accepted";
         }
     }
