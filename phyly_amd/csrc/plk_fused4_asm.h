@@ -12,7 +12,8 @@
  * Program format (built by prepare_stream_asm in plk_engine.hip): 32-bit op words in
  * blocks of 8, fetched a whole block ahead with one s_load_dwordx8;
  *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 MATVEC + TIP_MUL in one word, 5 TIP_MUL without wait, 6 SCALE, 7 END, 8 + d PUSH to
- *   stack slot d, 16 + d POPMUL of slot d), bits 15:5 field y, bits 31:16 field z
+ *   stack slot d, 16 + d POPMUL of slot d, 24 + d / 28 + d MATVEC followed by PUSH / POPMUL of slot d < 4 when the
+ *   tree needs at most 4 slots), bits 15:5 field y, bits 31:16 field z
  *   MATVEC            x = P x; matrices are consumed in stream order, the next one is
  *                     requested as soon as the current one has been used
  *   TIP_SET / TIP_MUL x (*)= tip value of this observation, which was fetched from LDS
@@ -81,6 +82,28 @@
     PLK_ASM_VPOP(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_VPOP(62, 63, 64, 65, 66, 67, 68, 69)               \
     PLK_ASM_VPOP(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_VPOP(78, 79, 80, 81, 82, 83, 84, 85)               \
     PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED
+/* handler indices 24..27: MATVEC + PUSH slot d, 28..31: MATVEC + POPMUL slot d (d < 4), one op word each */
+#define PLK_ASM_MV_VPUSH(A0, A1, B0, B1, C0, C1, E0, E1)                                  \
+    PLK_H_ALIGN PLK_ASM_MATVEC_CORE                                                       \
+    "v_mov_b64 v[" #A0 ":" #A1 "], v[24:25]\n\t"                                          \
+    "v_mov_b64 v[" #B0 ":" #B1 "], v[26:27]\n\t"                                          \
+    "v_mov_b64 v[" #C0 ":" #C1 "], v[28:29]\n\t"                                          \
+    "v_mov_b64 v[" #E0 ":" #E1 "], v[30:31]\n\t"                                          \
+    "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_MV_VPOP(A0, A1, B0, B1, C0, C1, E0, E1)                                   \
+    PLK_H_ALIGN PLK_ASM_MATVEC_CORE                                                       \
+    "v_mul_f64 v[24:25], v[24:25], v[" #A0 ":" #A1 "]\n\t"                                \
+    "v_mul_f64 v[26:27], v[26:27], v[" #B0 ":" #B1 "]\n\t"                                \
+    "v_mul_f64 v[28:29], v[28:29], v[" #C0 ":" #C1 "]\n\t"                                \
+    "v_mul_f64 v[30:31], v[30:31], v[" #E0 ":" #E1 "]\n\t"                                \
+    "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_SLOTS_D4_PAIRS                                                                            \
+    PLK_ASM_MV_VPUSH(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_MV_VPUSH(62, 63, 64, 65, 66, 67, 68, 69)       \
+    PLK_ASM_MV_VPUSH(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_MV_VPUSH(78, 79, 80, 81, 82, 83, 84, 85)       \
+    PLK_ASM_MV_VPOP(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_MV_VPOP(62, 63, 64, 65, 66, 67, 68, 69)         \
+    PLK_ASM_MV_VPOP(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_MV_VPOP(78, 79, 80, 81, 82, 83, 84, 85)
+#define PLK_ASM_SLOTS_D8_PAIRS  /* the deeper stack's programs do not use the pair words */ \
+    PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED PLK_H_UNUSED
 #define PLK_CLOBBER_V54_85 "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", \
     "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85"
 
@@ -114,6 +137,30 @@
     PLK_ASM_POP(32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_POP(40, 41, 42, 43, 44, 45, 46, 47)   \
     PLK_ASM_POP(48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_POP(56, 57, 58, 59, 60, 61, 62, 63)
 
+/* x = M x in place with the current matrix of the stream, then request the next one */
+#define PLK_ASM_MATVEC_CORE                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
+        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
+        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
+        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"                        \
+        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
+        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
+        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
+        "s_add_u32 s86, s86, 0x80\n\t"                                                \
+        "s_addc_u32 s87, s87, 0\n\t"                                                  \
+        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
+        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"
+
 /* the tail of an observation handler: request the value of the next observation op and the code of the one after */
 #define PLK_ASM_TIPNEXT                                                               \
         "s_bfe_u32 s98, s96, 0xb0005\n\t"                                             \
@@ -136,7 +183,7 @@
         "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
         "v_mul_f64 v[30:31], v[30:31], v[52:53]\n\t"
 
-#define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS)                                        \
+#define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS, PAIR_SLOTS)                                        \
         /* ---- prologue: operands into the fixed registers ---- */                   \
         "v_mov_b32 v24, %[x0lo]\n\tv_mov_b32 v25, %[x0hi]\n\t"                        \
         "v_mov_b32 v26, %[x1lo]\n\tv_mov_b32 v27, %[x1hi]\n\t"                        \
@@ -198,52 +245,12 @@
         PLK_ASM_TIPNEXT                                                               \
         /* ---- 2 MATVEC: x = M x in place ---- */                                    \
         PLK_H_ALIGN                                                                   \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
-        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
-        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
-        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
-        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
-        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
-        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
-        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
-        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
-        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
-        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"                        \
-        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
-        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
-        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
-        "s_add_u32 s86, s86, 0x80\n\t"                                                \
-        "s_addc_u32 s87, s87, 0\n\t"                                                  \
-        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
-        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
+        PLK_ASM_MATVEC_CORE                                                           \
         "s_setpc_b64 s[88:89]\n"                                                      \
         /* ---- 3 (+ the space of 4) MATVEC followed by TIP_MUL: one op word, one dispatch.  The product's wait covers
          * the prefetched tip value, and the word carries the observation's fields ---- */ \
         PLK_H_ALIGN                                                                   \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
-        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
-        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
-        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
-        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
-        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
-        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
-        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
-        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
-        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
-        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
-        "v_fma_f64 v[24:25], s[60:61], v[30:31], v[32:33]\n\t"                        \
-        "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
-        "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
-        "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
-        "s_add_u32 s86, s86, 0x80\n\t"                                                \
-        "s_addc_u32 s87, s87, 0\n\t"                                                  \
-        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
-        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"                                \
+        PLK_ASM_MATVEC_CORE                                                           \
         PLK_ASM_TIPMUL                                                                \
         PLK_ASM_TIPNEXT                                                               \
         /* (the pair handler is between 256 and 512 bytes long, so the next 256-byte boundary is handler 5's) */ \
@@ -271,6 +278,8 @@
         /* ---- 8..15 PUSH slot d, 16..23 POPMUL slot d ---- */                       \
         PUSH_SLOTS                                                                    \
         POP_SLOTS                                                                     \
+        /* ---- 24..31 MATVEC + PUSH / POPMUL of slots 0..3 ---- */                   \
+        PAIR_SLOTS                                                                    \
         /* ---- epilogue ---- */                                                      \
         PLK_H_ALIGN                                                                   \
         ".Ldone_%=:\n\t"                                                              \
@@ -321,10 +330,10 @@ __device__ __forceinline__ void fused_run_program_asm(double &x0, double &x1, do
     int x0lo = __double2loint(x0), x0hi = __double2hiint(x0), x1lo = __double2loint(x1), x1hi = __double2hiint(x1);
     int x2lo = __double2loint(x2), x2hi = __double2hiint(x2), x3lo = __double2loint(x3), x3hi = __double2hiint(x3);
     if constexpr (D <= 4) {
-        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH)
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH, PLK_ASM_SLOTS_D4_PAIRS)
                      PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_V54_85);
     } else {
-        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH)
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH, PLK_ASM_SLOTS_D8_PAIRS)
                      PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
     }
     x0 = __hiloint2double(x0hi, x0lo); x1 = __hiloint2double(x1hi, x1lo);

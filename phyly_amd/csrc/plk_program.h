@@ -277,6 +277,13 @@ static inline void plk_fused_build(int N, const PlkProgram &pg, PlkFused &fu)
                 continue;
             }
             matvec_since_obs = true;
+            if ((nx == OP_PUSH || nx == OP_POPMUL) && pg.slots_needed <= 4) {
+                /* MATVEC followed by PUSH / POPMUL (a node with two internal children): one word, handlers 24 + d /
+                 * 28 + d of the 4-slot interpreter */
+                fu.words[nw++] = (nx == OP_PUSH ? 24u : 28u) + (unsigned)fu.fops[pc + 1].y;
+                pc++;
+                continue;
+            }
         }
         if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
             const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
@@ -381,10 +388,11 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
             const size_t wi = b * 8 + i;
             const unsigned w = fu.words[wi];
             /* the kernel jumps to handler (w & 31): 0..7 = opcode (3 = MATVEC + TIP_MUL, occupying the slots of 3 and 4),
-             * 8 + d = PUSH slot d, 16 + d = POPMUL slot d */
+             * 8 + d = PUSH slot d, 16 + d = POPMUL slot d, 24 + d / 28 + d = MATVEC then PUSH / POPMUL slot d (4-slot
+             * interpreter only) */
             const unsigned hidx = w & 31, z = w >> 16;
-            if (hidx >= 24 || hidx == 4) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)wi);
-            const unsigned y = hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
+            if (hidx == 4 || (hidx >= 24 && D != 4)) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)wi);
+            const unsigned y = hidx >= 24 ? (hidx & 3) : hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
             std::string bad;
             if (hidx == OP_END) {
                 if ((int)pc != nops) return plk_fmt("asm program: END at word %ld after %ld of the program's ops", (long)wi, (long)pc);
@@ -396,7 +404,8 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
             else if (hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT) bad = observation(wi, y, z, hidx == OP_TIP_SET, hidx == PLK_WORD_TIPMUL_NOWAIT);
             else if (hidx == OP_SCALE) { if ((int)pc >= nops || (pg.ops[pc].x & 0xff) != OP_SCALE) bad = plk_fmt("asm program: word %ld is not the program's op", (long)wi); pc++; }
             else {
-                const bool push = hidx < 16;
+                if (hidx >= 24) { bad = product(wi); if (!bad.empty()) return bad; }         /* MATVEC + PUSH / POPMUL */
+                const bool push = hidx >= 24 ? hidx < 28 : hidx < 16;
                 if ((int)pc >= nops || (pg.ops[pc].x & 0xff) != (push ? OP_PUSH : OP_POPMUL) || (int)y >= D || (int)y != pg.ops[pc].y || (full[y] != 0) == push)
                     bad = plk_fmt(push ? "asm program: bad PUSH at word %ld" : "asm program: bad POPMUL at word %ld", (long)wi);
                 else full[y] = push;
