@@ -170,10 +170,8 @@
         "s_mul_i32 s97, s97, s94\n\t"                                                 \
         "v_bfe_u32 v43, v41, v45, s35\n\t"                                           \
         "v_lshl_add_u32 v40, v43, 5, s98\n\t"                                         \
-        "ds_read_b64 v[46:47], v40\n\t"                                               \
-        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
-        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
-        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
+        "ds_read_b128 v[46:49], v40\n\t"                                              \
+        "ds_read_b128 v[50:53], v40 offset:16\n\t"                                    \
         "v_add_u32 v43, s97, v44\n\t"                                                 \
         "ds_read_u8 v41, v43\n\t"                                                     \
         "s_setpc_b64 s[88:89]\n"
@@ -205,10 +203,8 @@
         /* prefetch chain start: tip value of the first observation, code of the second */ \
         "v_bfe_u32 v43, %[ch], v45, s35\n\t"                                         \
         "v_lshl_add_u32 v40, v43, 5, %[firsttip]\n\t"                                 \
-        "ds_read_b64 v[46:47], v40\n\t"                                               \
-        "ds_read_b64 v[48:49], v40 offset:8\n\t"                                      \
-        "ds_read_b64 v[50:51], v40 offset:16\n\t"                                     \
-        "ds_read_b64 v[52:53], v40 offset:24\n\t"                                     \
+        "ds_read_b128 v[46:49], v40\n\t"                                              \
+        "ds_read_b128 v[50:53], v40 offset:16\n\t"                                    \
         "ds_read_u8 v41, %[secaddr]\n\t"                                              \
         "s_getpc_b64 s[90:91]\n"                                                      \
         ".Lpcref_%=:\n\t"                                                             \
