@@ -245,6 +245,15 @@ def main():
                                  "leaf-edge products through tip tables, so executed flops are about half of W_ll"
                                  % (alg["W_ll"], kern_count),
                             hbm_model_equiv=hbm_model)
+            # executed work: internal edges are full products (k^2 multiplies + k(k-1) fused multiply-adds), a leaf costs
+            # one k-wide multiply by its table row; what the fp64 pipe really issued, against the same peak
+            k_, T_, C_ = wl.k, wl.T, wl.prepare()["C"]
+            kpad = k_ if kernel_kind != 3 else ((k_ + 15) // 16) * 16
+            exec_flops = C_ * ((wl.E - T_) * (2 * kpad * kpad - kpad) + T_ * k_)
+            roofline["executed"] = dict(flops_per_site=exec_flops, achieved=exec_flops * S / kern_s / 1e12,
+                                        frac=exec_flops * S / kern_s / FP64_PEAK,
+                                        note="C x ((E - T) internal-edge products of 2k^2 - k flops (k padded to 16 rows on the "
+                                             "matrix cores) + T leaf multiplies of k flops); stack and rescaling work not counted")
         else:
             roofline = dict(bound="hbm", achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                             frac=hbm_equiv / HBM_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
