@@ -83,3 +83,33 @@ def test_current_build_is_clean():
         pytest.skip("no lint report (library built elsewhere)")
     last = open(rep).read().strip().splitlines()[-1]
     assert " 0 violations" in last, last
+
+
+def test_handler_table_layout_check_accepts_the_build_and_rejects_an_overlong_handler(tmp_path):
+    """tools/asm_layout_check.py (part of the build): the k = 4 assembly interpreter jumps to table + 256 * index, so a
+    handler must not outgrow its 256-byte slot.  The built object passes; a synthetic listing in which a handler runs
+    across a slot boundary is rejected (the check is fed through its own parser, no assembler needed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_layout_check", os.path.join(ROOT, "tools", "asm_layout_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    obj = os.path.join(ROOT, "phyly_amd", "csrc", "build", "plk_engine-hip-amdgcn-amd-amdhsa-gfx950.o")
+    if os.path.exists(obj) and os.path.exists(mod.OBJDUMP):
+        assert mod.main(obj) == 0
+
+    def table(overlong_slot):
+        ins, a = [(0x1ffc, "s_nop")], 0x2000
+        for slot in range(mod.NSLOTS):
+            n = 70 if slot == overlong_slot else (68 if slot == 3 else 10)     # 4-byte instructions: 70 > 64 per slot
+            end = a + 4 * n
+            while a < end - 4:
+                ins.append((a, "v_fma_f64")); a += 4
+            ins.append((a, "s_setpc_b64")); a += 4
+            nxt = 0x2000 + 256 * (slot + 1) if slot != 3 else a               # slot 3 runs on into slot 4
+            while a < nxt:
+                ins.append((a, "s_nop")); a += 4
+        ins.append((a, "s_waitcnt"))
+        return ins
+    assert mod.check("good", table(-1)) == []
+    bad = mod.check("bad", table(9))
+    assert bad and "slot 9 runs into slot 10" in bad[0]
