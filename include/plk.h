@@ -215,10 +215,12 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
        PLK_OPT_FUSED_ASM = 3 /* 1 (default): assembly interpreter loop where applicable, 0: C++ loop */,
        PLK_OPT_MFMA = 4 /* 1 (default): register-resident vector kernel for 9 <= k <= 32, fp64 matrix-core kernel for
                            33 <= k <= 64; 2: matrix-core kernel for all of 9 <= k <= 64; 0: generic vector kernel */,
-       PLK_OPT_UP_NODES = 5 /* 1: derivative queries on the matrix-core kernels (21 <= k <= 64, or all of 9 <= k <= 64 under
-                               PLK_OPT_MFMA = 2) use the node-visit up pass over stored edge vectors (fewer HBM bytes, same
-                               speed as measured in round 2); 0 (default): the one-edge-at-a-time up pass that marginal
-                               queries use too.  ARBPLF_UP_NODES in the environment sets the initial value. */ };
+       PLK_OPT_UP_NODES = 5 /* node-visit up pass for derivative queries, a bit per kernel family (default 2):
+                               bit 1 (2): k = 4 kernels (k_up4_nodes: a third fewer HBM bytes than k_up4);
+                               bit 0 (1): matrix-core kernels, 21 <= k <= 64 or all of 9 <= k <= 64 under PLK_OPT_MFMA = 2
+                               (k_up_nodes_mfma: fewer HBM bytes, same speed as measured in round 2).
+                               Marginal queries always take the one-edge-at-a-time passes.  ARBPLF_UP_NODES in the
+                               environment sets the initial value. */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

@@ -127,7 +127,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 0;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
@@ -1851,7 +1851,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
      * (k_up_nodes_mfma), when the depth-first down pass applies (its staged code rows fit the LDS).  Measured equal to
      * k_up_mfma at BASELINE config 5 (32.1 against 31.7 ms per step: the down pass gains what the up pass loses), so
      * not the default; DESIGN.md section 4 has the counters */
-    const bool nodes = deriv && !marg && h->opt_up_nodes &&
+    const bool nodes = deriv && !marg && (h->opt_up_nodes & 1) &&
                        (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)MF_SITES <= 60 * 1024;
     PlkUpNodes un;
     if (nodes) {
@@ -2014,6 +2014,18 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     }
     const std::vector<plk_op4> &ops2 = ch2.ops;
     const int first_slot2 = ch2.first_slot, first_row2 = ch2.first_row;
+    /* derivative queries (one edge form, no marginals, at most 4 rate categories): node-visit up pass k_up4_nodes, which
+     * keeps the vector of a continued child in registers for all categories; PLK_OPT_UP_NODES bit 1 switches it off */
+    const bool nodes4 = deriv && !marg && nM == 1 && C <= 4 && E > 0 && (h->opt_up_nodes & 2);
+    PlkUpNodes un4;
+    if (nodes4) {
+        if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+        plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
+                           node_int.data(), node_scale.data(), edge_mask, un4);
+        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc);
+        if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+    }
+    const int *d_vis4 = nullptr;
     double *d_tip4 = nullptr, *d_dtip4 = nullptr;
     auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
@@ -2029,6 +2041,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         const size_t o_oe = put(h->op_edge.data(), h->op_edge.size()), o_obs = put(h->obs_nodes.data(), h->obs_nodes.size());
         const size_t o_inl = put(node_inline.data(), (size_t)N);
         const size_t o_em = edge_mask && E > 0 ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
+        const size_t o_vis = nodes4 ? put(un4.rec.data(), un4.rec.size()) : 0;
         if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4))) return rc;
         if ((rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, ntab * (size_t)(1 + nM)))) return rc;
         HIPCHK(h, hipMemcpyAsync(h->d_u4pack, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -2039,6 +2052,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         d_oe2 = b + o_oe; d_obs2 = b + o_obs; d_inl = b + o_inl;
         d_emask = edge_mask && E > 0 ? b + o_em : nullptr;
         d_nmask = node_mask ? b + o_nm : nullptr;
+        d_vis4 = nodes4 ? b + o_vis : nullptr;
         d_tip4 = h->d_u4tip; d_dtip4 = h->d_u4tip + ntab;
     }
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
@@ -2079,7 +2093,9 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)ER * n;
         a.MV = p; if (marg) p += (size_t)N * 4 * n;
-        if (deriv && E > 0) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
+        a.visits = d_vis4; a.nvisits = un4.nvisits;
+        /* (the node-visit pass writes the row of every wanted edge: rows need clearing only under a mask) */
+        if (deriv && E > 0 && !(nodes4 && !edge_mask)) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
         const size_t lds_codes = (size_t)nobs2 * UD4_BLOCK;
@@ -2088,7 +2104,9 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         else if (fused_ok && h->slots_needed <= 8) hipLaunchKernelGGL(k_down_fused4<8>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
         else if (fused_ok && h->slots_needed <= 16) hipLaunchKernelGGL(k_down_fused4<16>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
         else hipLaunchKernelGGL(k_down_store4, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
-        if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        if (nodes4 && C == 1) hipLaunchKernelGGL(k_up4_nodes<1>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (nodes4) hipLaunchKernelGGL(k_up4_nodes<4>, dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
+        else if (deriv && marg) hipLaunchKernelGGL((k_up4<true, true>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv && nM == 2) hipLaunchKernelGGL((k_up4<true, false, 2>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv && nM == 3) hipLaunchKernelGGL((k_up4<true, false, 3>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);
         else if (deriv && nM == 4) hipLaunchKernelGGL((k_up4<true, false, 4>), dim3(grid), dim3(UD4_BLOCK), 0, h->stream, a);

@@ -44,6 +44,8 @@ struct Up4Args {
     double *SC;                    /* [(slot*C + c)][n]: 2^-e applied to L_a at rescaled nodes */
     double *CW, *XC;               /* [C][n]: 2^(X_c - Xmax); scratch: X_c and category likelihood mantissas */
     double *LH, *DV, *MV;          /* [n] (at exponent Xmax), [E][n], [N][4][n] */
+    const int *visits;             /* k_up4_nodes: records of plk_up_nodes_build() (plk_program.h) */
+    int nvisits;
 };
 
 struct v4 { double a, b, c, d; };
@@ -582,6 +584,189 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                 mv[0] = macc.a * inv; mv[n] = macc.b * inv; mv[2 * n] = macc.c * inv; mv[3 * n] = macc.d * inv;
             }
         }
+    }
+}
+
+/*
+ * Up pass of the derivative query by node visits, k = 4 (records: plk_up_nodes_build() of plk_program.h; the scheme of
+ * k_up_nodes_mfma).  k_up4 stores the forward vector of every internal node and reads it back in the node's own visit:
+ * 47.7 GB read + 20.1 GB written per 2M sites at BASELINE config 3, at 6 TB/s -- the HBM roof.  Here what is stored per
+ * internal node is G_a, the vector at the top of the edge into a, visits run depth first, and the G of the last internal
+ * child with work stays in registers for the next visit (all C categories of it: 8 C registers, C <= CM), so a G is
+ * written and read only where the tree forks into two internal subtrees.  A visit reads L_b once per internal child,
+ * recomputes the child messages (16 FMAs), finishes the derivative of a's own edge as (M_a^T G_a) . (s_a B_a o messages)
+ * -- L_a itself is never read, and the constant-vector rule of src/util.c:338-345 is applied to the recomputed L_a
+ * exactly --, forms F_a = P_a^T G_a and the G of every child; leaf edges are finished with the edge-form tip tables.
+ * Categories run inside the visit, so every edge's derivative is written once (no read-modify-write of DV).
+ */
+/* "SGPR base + 32-bit lane offset" forms of ld4 / st4 and of scalar element access: the (wave-uniform) base is pinned in an
+ * SGPR pair, so that no 64-bit lane address per array is kept across the visit loop (k_up4_nodes: 40 of them otherwise) */
+__device__ __forceinline__ v4 ld4u(const double *base, unsigned off)
+{
+    asm volatile("" : "+s"(base));
+    const double2 *p = reinterpret_cast<const double2 *>(base);
+    const double2 lo = p[off >> 1], hi = p[(off >> 1) + 1];
+    return v4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void st4u(double *base, unsigned off, const v4 &v)
+{
+    asm volatile("" : "+s"(base));
+    double2 *p = reinterpret_cast<double2 *>(base);
+    p[off >> 1] = double2{v.a, v.b};
+    p[(off >> 1) + 1] = double2{v.c, v.d};
+}
+template <class V>
+__device__ __forceinline__ V at_u(const V *base, unsigned off)
+{
+    asm volatile("" : "+s"(base));
+    return base[off];
+}
+
+template <int CM>
+__global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up4_nodes(Up4Args a)
+{
+    const long sl = (long)blockIdx.x * UD4_BLOCK + threadIdx.x;
+    const bool valid = sl < a.n;
+    const long slc = valid ? sl : a.n - 1;
+    const unsigned us = (unsigned)slc, us4 = us * 4u;          /* lane offsets: site, and site x 4 doubles */
+    const size_t n = (size_t)a.n;
+    const PLK_AS4 int *vis = as_uniform(a.visits);
+    const PLK_AS4 double *Pm = as_uniform(a.P), *Mm = as_uniform(a.dP);
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
+    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * 4;
+    const double inv = 1.0 / at_u(a.LH, us);
+    const v4 one = v4{1.0, 1.0, 1.0, 1.0};
+    double pcw[CM];                           /* prior_c x 2^(X_c - Xmax) */
+#pragma unroll
+    for (int c = 0; c < CM; c++) pcw[c] = c < a.C ? prior[c] * at_u(a.CW + (size_t)c * n, us) : 0.0;
+    v4 gc[CM];                                /* G handed from visit to visit in registers, per category (consumed, then re-formed in place) */
+#pragma unroll
+    for (int c = 0; c < CM; c++) gc[c] = v4{rw[0], rw[1], rw[2], rw[3]};     /* the root's visit comes first */
+
+    int vp = 0;
+    for (int v = 0; v < a.nvisits; v++) {
+        const int nd = vis[vp], deg = vis[vp + 1], nd_int = vis[vp + 2], slot = vis[vp + 3], hd = vis[vp + 4], e0 = vis[vp + 5];
+        const int ea = vis[vp + 6], hfl = vis[vp + 7];
+        const PLK_AS4 int *ch = vis + vp + 8;
+        vp += 8 + 4 * deg;
+        const int code_nd = hd ? at_u(a.codes + (size_t)nd * a.Spad + a.s0, us) : 0;
+        /* message of the child in record J for category C_: tip-table row, or P_b L_b (L_b constant: the constant) */
+#define U4N_MESSAGE(J, C_, M)                                                                             \
+        do { const int b_ = ch[4 * (J)], t_ = ch[4 * (J) + 1], pos_ = ch[4 * (J) + 2] >> PLK_UN_POS_SHIFT; \
+             if (t_ >= 0) M = ld4u(a.tip + (size_t)(C_) * tabc + (size_t)t_ * a.nchar * 4, 4u * at_u(a.codes + (size_t)b_ * a.Spad + a.s0, us)); \
+             else { const v4 x_ = ld4u(a.LN + ((size_t)ch[4 * (J) + 3] * a.C + (C_)) * n * 4, us4);        \
+                    M = mv4(Pm + ((size_t)(C_) * a.E + e0 + pos_) * 16, x_);                              \
+                    if (const4(x_)) M = x_; } } while (0)
+        if (deg <= 2) {
+            double d_own = 0.0, d0 = 0.0, d1 = 0.0;
+            const int fl0 = ch[2], fl1 = deg == 2 ? ch[6] : 0;
+            /* pattern codes of leaf children, once per visit */
+            const unsigned cd0 = ch[1] >= 0 ? 4u * at_u(a.codes + (size_t)ch[0] * a.Spad + a.s0, us) : 0u;
+            const unsigned cd1 = deg == 2 && ch[5] >= 0 ? 4u * at_u(a.codes + (size_t)ch[4] * a.Spad + a.s0, us) : 0u;
+#pragma unroll
+            for (int c = 0; c < CM; c++) {
+                if (c >= a.C) break;
+                const double *tipc = a.tip + (size_t)c * tabc, *dtipc = a.dtip + (size_t)c * tabc;
+                v4 g = gc[c];
+                if (!(hfl & PLK_UN_FROM_REGS)) g = ld4u(a.FN + ((size_t)nd_int * a.C + c) * n * 4, us4);
+                const double sc = slot >= 0 ? at_u(a.SC + ((size_t)slot * a.C + c) * n, us) : 1.0;
+                v4 m0, m1 = one, ob = one;
+                if (ch[1] >= 0) m0 = ld4u(tipc + (size_t)ch[1] * a.nchar * 4, cd0);
+                else {
+                    const v4 x = ld4u(a.LN + ((size_t)ch[3] * a.C + c) * n * 4, us4);
+                    m0 = mv4(Pm + ((size_t)c * a.E + e0 + (fl0 >> PLK_UN_POS_SHIFT)) * 16, x);
+                    if (const4(x)) m0 = x;
+                }
+                if (deg == 2) {
+                    if (ch[5] >= 0) m1 = ld4u(tipc + (size_t)ch[5] * a.nchar * 4, cd1);
+                    else {
+                        const v4 x = ld4u(a.LN + ((size_t)ch[7] * a.C + c) * n * 4, us4);
+                        m1 = mv4(Pm + ((size_t)c * a.E + e0 + (fl1 >> PLK_UN_POS_SHIFT)) * 16, x);
+                        if (const4(x)) m1 = x;
+                    }
+                }
+                if (hd) ob = ld4u(tipc + (size_t)a.ntips * a.nchar * 4, 4u * (unsigned)code_nd);
+                if (hfl & PLK_UN_OWN_D) {
+                    const v4 z = mtv4(Mm + ((size_t)c * a.E + ea) * 16, g);
+                    const v4 l = mul4(mul4(m0, m1), ob);                 /* L_a / s_a */
+                    const double d = (a.dzero && const4(l)) ? 0.0 : fma(z.d, l.d, fma(z.c, l.c, fma(z.b, l.b, z.a * l.a)));
+                    d_own = fma(pcw[c] * sc, d, d_own);
+                }
+                v4 fe = ea >= 0 ? mtv4(Pm + ((size_t)c * a.E + ea) * 16, g) : g;
+                fe = mul4(fe, ob);
+                fe.a *= sc; fe.b *= sc; fe.c *= sc; fe.d *= sc;
+                const v4 g0 = mul4(fe, m1), g1 = mul4(fe, m0);        /* child 0 sees child 1's message and vice versa */
+                if (fl0 & PLK_UN_LEAF_D) {
+                    const v4 y = ld4u(dtipc + (size_t)ch[1] * a.nchar * 4, cd0);
+                    d0 = fma(pcw[c], fma(g0.d, y.d, fma(g0.c, y.c, fma(g0.b, y.b, g0.a * y.a))), d0);
+                } else if ((fl0 & PLK_UN_STORE_G) && valid) st4u(a.FN + ((size_t)ch[3] * a.C + c) * n * 4, us4, g0);
+                if (fl1 & PLK_UN_LEAF_D) {
+                    const v4 y = ld4u(dtipc + (size_t)ch[5] * a.nchar * 4, cd1);
+                    d1 = fma(pcw[c], fma(g1.d, y.d, fma(g1.c, y.c, fma(g1.b, y.b, g1.a * y.a))), d1);
+                } else if ((fl1 & PLK_UN_STORE_G) && valid) st4u(a.FN + ((size_t)ch[7] * a.C + c) * n * 4, us4, g1);
+                /* the continued child is the last record: record 1 of two, record 0 of one */
+                gc[c] = deg == 2 ? g1 : g0;
+                /* one category at a time: interleaving the unrolled categories (all loads first) needs 176 VGPRs */
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (valid) {
+                if (hfl & PLK_UN_OWN_D) { double *dp = a.DV + (size_t)ea * n; asm volatile("" : "+s"(dp)); dp[us] = d_own * inv; }
+                if (fl0 & PLK_UN_LEAF_D) { double *dp = a.DV + (size_t)(e0 + (fl0 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = d0 * inv; }
+                if (fl1 & PLK_UN_LEAF_D) { double *dp = a.DV + (size_t)(e0 + (fl1 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = d1 * inv; }
+            }
+        } else {
+            /* more than two children: messages recomputed per child (as the one-edge-at-a-time pass does); one child at
+             * a time over all categories, so that its derivative is still written once */
+            double d_own = 0.0;
+            v4 fe[CM];
+#pragma unroll
+            for (int c = 0; c < CM; c++) fe[c] = one;        /* defined for every c, also past a.C (one definition dominating the uses) */
+#pragma unroll
+            for (int c = 0; c < CM; c++) {
+                if (c >= a.C) break;
+                const double *tipc = a.tip + (size_t)c * tabc;
+                v4 g = gc[c];
+                if (!(hfl & PLK_UN_FROM_REGS)) g = ld4u(a.FN + ((size_t)nd_int * a.C + c) * n * 4, us4);
+                const double sc = slot >= 0 ? at_u(a.SC + ((size_t)slot * a.C + c) * n, us) : 1.0;
+                const v4 ob = hd ? ld4u(tipc + (size_t)a.ntips * a.nchar * 4, 4u * (unsigned)code_nd) : one;
+                if (hfl & PLK_UN_OWN_D) {
+                    const v4 z = mtv4(Mm + ((size_t)c * a.E + ea) * 16, g);
+                    v4 l = ob;
+                    for (int j = 0; j < deg; j++) { v4 m; U4N_MESSAGE(j, c, m); l = mul4(l, m); }
+                    const double d = (a.dzero && const4(l)) ? 0.0 : fma(z.d, l.d, fma(z.c, l.c, fma(z.b, l.b, z.a * l.a)));
+                    d_own = fma(pcw[c] * sc, d, d_own);
+                }
+                v4 f = ea >= 0 ? mtv4(Pm + ((size_t)c * a.E + ea) * 16, g) : g;
+                f = mul4(f, ob);
+                f.a *= sc; f.b *= sc; f.c *= sc; f.d *= sc;
+                fe[c] = f;
+            }
+            if (valid && (hfl & PLK_UN_OWN_D)) { double *dp = a.DV + (size_t)ea * n; asm volatile("" : "+s"(dp)); dp[us] = d_own * inv; }
+            for (int j = 0; j < deg; j++) {
+                const int fl = ch[4 * j + 2];
+                if (!(fl & PLK_UN_WORK)) continue;
+                double dj = 0.0;
+                const unsigned cdj = ch[4 * j + 1] >= 0 ? 4u * at_u(a.codes + (size_t)ch[4 * j] * a.Spad + a.s0, us) : 0u;
+#pragma unroll
+                for (int c = 0; c < CM; c++) {
+                    if (c >= a.C) break;
+                    v4 gb = fe[c];
+                    for (int j2 = 0; j2 < deg; j2++) {
+                        if (j2 == j) continue;
+                        v4 m;
+                        U4N_MESSAGE(j2, c, m);
+                        gb = mul4(gb, m);
+                    }
+                    if (fl & PLK_UN_LEAF_D) {
+                        const v4 y = ld4u(a.dtip + (size_t)c * tabc + (size_t)ch[4 * j + 1] * a.nchar * 4, cdj);
+                        dj = fma(pcw[c], fma(gb.d, y.d, fma(gb.c, y.c, fma(gb.b, y.b, gb.a * y.a))), dj);
+                    } else if ((fl & PLK_UN_STORE_G) && valid) st4u(a.FN + ((size_t)ch[4 * j + 3] * a.C + c) * n * 4, us4, gb);
+                    gc[c] = gb;                       /* the continued child is the last record */
+                }
+                if (valid && (fl & PLK_UN_LEAF_D)) { double *dp = a.DV + (size_t)(e0 + (fl >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = dj * inv; }
+            }
+        }
+#undef U4N_MESSAGE
     }
 }
 
