@@ -706,8 +706,6 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 } else if ((fl1 & PLK_UN_STORE_G) && valid) st4u(a.FN + ((size_t)ch[7] * a.C + c) * n * 4, us4, g1);
                 /* the continued child is the last record: record 1 of two, record 0 of one */
                 gc[c] = deg == 2 ? g1 : g0;
-                /* one category at a time: interleaving the unrolled categories (all loads first) needs 176 VGPRs */
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (valid) {
                 if (hfl & PLK_UN_OWN_D) { double *dp = a.DV + (size_t)ea * n; asm volatile("" : "+s"(dp)); dp[us] = d_own * inv; }
