@@ -192,7 +192,7 @@ def test_node_visit_up_pass_equals_edge_up_pass(eng, oracle):
         eng.set_option(E.OPT_UP_NODES, nodes)
         eng.set_option(E.OPT_SITE_CHUNK, 128)
         out[nodes] = (eng.deriv()[0], eng.deriv(edge_mask=mask)[0])
-    eng.set_option(E.OPT_UP_NODES, 0)
+    eng.set_option(E.OPT_UP_NODES, 2)          # the default: k = 4 node visits on, matrix-core node visits off
     eng.set_option(E.OPT_SITE_CHUNK, 0)
     for q in (0, 1):
         scale = np.max(np.abs(out[0][q]), axis=1, keepdims=True)
@@ -206,3 +206,33 @@ def test_node_visit_up_pass_equals_edge_up_pass(eng, oracle):
     m, ow = oracle_model(oracle, w, codes[:, :nq])
     want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes[:, :nq]), precise=1)
     assert _row_err(out[1][0][:nq], want) <= 1e-12
+
+
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_k4_node_visit_up_pass_equals_edge_up_pass(eng, oracle, cfg):
+    """k = 4 derivative queries: k_up4_nodes (default, PLK_OPT_UP_NODES bit 1) against k_up4 (bit cleared) and the
+    oracle; all edges and a sparse edge mask, several site chunks"""
+    from phyly_amd import synth, engine as E
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    S = 700
+    codes = w.random_codes(S, seed=cfg)
+    eng.set_patterns_codes(codes, w.defs)
+    eng.set_site_weights(None)
+    mask = np.zeros(w.E, dtype=np.int32)
+    mask[[0, 5, w.E // 2, w.E - 1]] = 1
+    out = {}
+    for nodes in (2, 0):
+        eng.set_option(E.OPT_UP_NODES, nodes)
+        eng.set_option(E.OPT_SITE_CHUNK, 256)
+        out[nodes] = (eng.deriv()[0], eng.deriv(edge_mask=mask)[0])
+    eng.set_option(E.OPT_UP_NODES, 2)
+    eng.set_option(E.OPT_SITE_CHUNK, 0)
+    for q in (0, 1):
+        scale = np.max(np.abs(out[0][q]), axis=1, keepdims=True)
+        assert np.max(np.abs(out[2][q] - out[0][q]) / np.maximum(scale, 1e-300)) <= 1e-13
+    sel = mask.astype(bool)
+    assert np.all(out[2][1][:, ~sel] == 0.0)
+    m, ow = oracle_model(oracle, w, codes[:, :60])
+    want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes[:, :60]), precise=2)
+    assert _row_err(out[2][0][:60], want) <= 1e-12
