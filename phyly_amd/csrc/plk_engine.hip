@@ -2014,9 +2014,10 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     }
     const std::vector<plk_op4> &ops2 = ch2.ops;
     const int first_slot2 = ch2.first_slot, first_row2 = ch2.first_row;
-    /* derivative queries (one edge form, no marginals, at most 4 rate categories): node-visit up pass k_up4_nodes, which
+    /* derivative queries proper (edge form dP, no marginals, at most 4 rate categories; the expectation queries keep k_up4,
+     * whose several-forms-per-pass variant they must agree with bit for bit): node-visit up pass k_up4_nodes, which
      * keeps the vector of a continued child in registers for all categories; PLK_OPT_UP_NODES bit 1 switches it off */
-    const bool nodes4 = deriv && !marg && nM == 1 && C <= 4 && E > 0 && (h->opt_up_nodes & 2);
+    const bool nodes4 = deriv && !marg && nM == 1 && dzero && C <= 4 && E > 0 && (h->opt_up_nodes & 2);
     PlkUpNodes un4;
     if (nodes4) {
         if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
