@@ -2166,8 +2166,12 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     for (int a = 0; a < N; a++) if (h->indptr[a + 1] > h->indptr[a]) node_int[a] = nin++;
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
     /* down-pass program and up-pass visit records + matrix list, both checked before anything is launched */
+    /* nodes finished inside their parent's visit (no marginals asked for): the up pass rebuilds their L vector from the
+     * tip tables, so the down pass does not store it (a third of the stored vectors at BASELINE config 4) */
+    std::vector<char> skip_l(N, 0);
+    for (int u = 1; u < N; u++) { const int b = h->preorder[u]; skip_l[b] = plk_up_inlinable(h->indptr.data(), edge_tip.data(), b, marg); }
     PlkChain ch;
-    plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch);
+    plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch, skip_l.data());
     PlkUpVisits uv;
     plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
                         node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);

@@ -475,7 +475,7 @@ struct PlkChain {
  * child node, w = CSR edge of the next MATVEC, wrapping to the first (k_down_fused4, k_down_vec); mode 2: as 1 but
  * w = storage index of the edge (k_down_fused_mfma, no chain).  SCALE y = rescaling slot of the node or -1 (modes 1, 2). */
 static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const int *indices, const int *node_int,
-                                   const int *edge_int, const int *node_scale, PlkChain &ch)
+                                   const int *edge_int, const int *node_scale, PlkChain &ch, const char *skip_store = nullptr)
 {
     const int ntips = (int)pg.tip_edge.size();
     std::vector<int> row(N, -1);
@@ -497,6 +497,7 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
         } else if (code == OP_MATVEC && mode >= 1) {
             o.y = pg.op_edge[pc];
             o.z = node_int ? node_int[indices[o.y]] : 0;
+            if (mode == 3 && skip_store && skip_store[indices[o.y]]) o.z = -1;      /* this child's vector is not stored */
             if (mode == 2) o.w = edge_int[o.y];
         } else if (code == OP_SCALE && mode >= 1 && node_scale) {
             o.y = node_scale[pg.ops[pc].y];
@@ -555,6 +556,16 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
  */
 enum { PLK_UP_WANT_D = 1, PLK_UP_WANT_F = 2, PLK_UP_WANT_M = 4, PLK_UP_STORE_F = 8, PLK_UP_INLINE = 16 };
 
+/* a node whose one or two children are all leaves is finished inside its parent's visit when no marginals are asked for:
+ * its forward vector is never stored, and neither is its L vector (the up pass rebuilds it from the tip tables) */
+static inline bool plk_up_inlinable(const int *ip, const int *edge_tip, int b, bool marg)
+{
+    const int d = ip[b + 1] - ip[b];
+    if (marg || d < 1 || d > 2) return false;
+    for (int idx = ip[b]; idx < ip[b + 1]; idx++) if (edge_tip[idx] < 0) return false;
+    return true;
+}
+
 struct PlkUpVisits {
     std::vector<int> rec;              /* visit records, then the inline records */
     size_t visit_ints = 0;             /* ints of rec taken by the visit records */
@@ -575,12 +586,7 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
         return (wd ? PLK_UP_WANT_D : 0) | (wf ? PLK_UP_WANT_F : 0) | (wm ? PLK_UP_WANT_M : 0) | (!leaf ? PLK_UP_STORE_F : 0);
     };
     auto put = [&](int kind, int edge) { uv.kind.push_back(kind); uv.edge.push_back(edge); };
-    auto inlinable = [&](int b) {
-        const int d = ip[b + 1] - ip[b];
-        if (marg || d < 1 || d > 2) return false;
-        for (int idx = ip[b]; idx < ip[b + 1]; idx++) if (edge_tip[idx] < 0) return false;
-        return true;
-    };
+    auto inlinable = [&](int b) { return plk_up_inlinable(ip, edge_tip, b, marg); };
     std::vector<int> inl;                /* inline records, appended after the visits */
     std::vector<size_t> fix;             /* positions in rec that hold an offset into inl */
     for (int u = 0; u < N; u++) {
@@ -837,7 +843,7 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
             do { nx = nx + 1 < nops ? nx + 1 : 0; } while ((pg.ops[nx].x & 0xff) != OP_MATVEC);
             if (o.z != nx) return plk_fmt("down program: op %ld names the wrong next product", pc);
         } else if (code == OP_MATVEC && mode >= 1) {
-            if (o.y != pg.op_edge[pc] || o.z < 0 || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
+            if (o.y != pg.op_edge[pc] || o.z < (mode == 3 && nint_nodes > 0 ? -1 : 0) || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
             if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
         } else if (code == OP_PUSH || code == OP_POPMUL) {
             if (o.y < 0 || o.y >= D) return "down program: stack slot out of range";

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
             if (code == OP_MATVEC) {
                 const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
                 /* the child's vector is final: store it, then multiply by its edge's P */
-                if (valid) udv_store<K>(a.LN + ((size_t)oz * a.C + c) * K * n, n, slc, cur);
+                if (valid && oz >= 0) udv_store<K>(a.LN + ((size_t)oz * a.C + c) * K * n, n, slc, cur);   /* oz < 0: rebuilt by the up pass */
                 vec_touch<K>(PTc + (size_t)ow * K * K);            /* lines of the next product's matrix */
                 const bool cst = udv_const<K>(cur, a.k);
                 const double x0 = cur[0];
@@ -268,6 +268,22 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
             const PLK_AS4 int *ch = vis + vp + 8;
             vp += 8 + 4 * deg;
             /* accumulate over categories in the output planes: first category writes, later ones add */
+            /* L vector of internal child B_ (child record fields T_, BI_) into OUT: read from LN, or -- for a child that is
+             * finished inside this visit (T_ <= -2: its record q lists its one or two leaves) -- rebuilt from the tip
+             * tables in the order the down pass multiplied it (leaf rows, own observation, rescaling factor): the same
+             * bits, and the down pass does not store it */
+#define UDV_CHILD_L(B_, T_, BI_, OUT)                                                                     \
+            do { if ((T_) > -2) udv_load<K>(a.LN + ((size_t)(BI_) * a.C + c) * K * n, n, slc, OUT);      \
+                 else { const PLK_AS4 int *q_ = vis + (-2 - (T_));                                        \
+                        udv_gather<K>(tipc + ((size_t)q_[6] * a.nchar + a.codes[(size_t)q_[5] * a.Spad + sg]) * K, OUT); \
+                        if (q_[3] == 2) { double r_[K];                                                   \
+                            udv_gather<K>(tipc + ((size_t)q_[9] * a.nchar + a.codes[(size_t)q_[8] * a.Spad + sg]) * K, r_); \
+                            _Pragma("unroll") for (int i = 0; i < K; i++) OUT[i] *= r_[i]; }              \
+                        if (q_[1]) { double r_[K];                                                        \
+                            udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)(B_) * a.Spad + sg]) * K, r_); \
+                            _Pragma("unroll") for (int i = 0; i < K; i++) OUT[i] *= r_[i]; }              \
+                        if (q_[2] >= 0) { const double s_ = a.SC[((size_t)q_[2] * a.C + c) * n + slc];   \
+                            _Pragma("unroll") for (int i = 0; i < K; i++) OUT[i] *= s_; } } } while (0)
 #define UDV_OUT_D(EDGE, VAL)                                                                              \
             do { if (valid) { double *dp_ = a.DV + (size_t)(EDGE) * n + sl;                               \
                  const double t_ = (VAL); *dp_ = (first_cat ? t_ : *dp_ + t_) * (last_cat ? inv : 1.0); } } while (0)
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (t2 >= 0) udv_gather<K>(tipc + ((size_t)t2 * a.nchar + a.codes[(size_t)b2 * a.Spad + sg]) * K, m);
                     else {
                         double L[K];
-                        udv_load<K>(a.LN + ((size_t)bi2 * a.C + c) * K * n, n, slc, L);
+                        UDV_CHILD_L(b2, t2, bi2, L);
                         vec_touch<K>(ms + 2 * KK);
                         vec_matvec<K>(ms, L, m);
                         ms += KK;
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (t >= 0) udv_gather<K>(dtipc + ((size_t)t * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, y);
                     else {
                         double L[K];
-                        udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, L);
+                        UDV_CHILD_L(b, t, bi, L);
                         vec_touch<K>(ms + 2 * KK);
                         vec_matvec<K>(ms, L, y);
                         ms += KK;
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
 #undef UDV_OUT_D
 #undef UDV_OUT_M
+#undef UDV_CHILD_L
     }
 }
 
