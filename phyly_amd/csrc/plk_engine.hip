@@ -224,6 +224,10 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
 }
 
 #define EXPM_TERMS 16     /* with |A| <= 2^-5 after scaling: 2^-80 / 16! < 1e-37, below double-double resolution */
+/* The degree-16 Taylor polynomial is evaluated by Paterson-Stockmeyer: powers A^2, A^3, A^4 (three products), then
+ * Horner in A^4 over the four cubic blocks B_i = c_4i I + c_4i+1 A + c_4i+2 A^2 + c_4i+3 A^3 (three more products) --
+ * 6 double-double matrix products instead of 15, before the squarings.  Six k x k buffers per matrix instead of four. */
+#define EXPM_BUFFERS 6
 
 /*
  * FRECHET = false: P = exp(s Qn), s = r_c t_e; outputs unrounded / rounded P and dP = r_c Qn P.
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
     extern __shared__ double smem_raw[];
     __shared__ double s_row[2 * PLK_MAX_K];
     __shared__ int s_sq;
+    __shared__ dd s_coef[EXPM_TERMS + 1];           /* 1 / n! in double-double */
     const int ce = blockIdx.x;
     const int c = ce / E, e = ce - c * E;
     const int k = FRECHET ? 2 * ks : ks;
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
         for (int idx = threadIdx.x; idx < kks; idx += blockDim.x) Fout[(size_t)ce * kks + idx] = 0.0;
         return;
     }
-    dd *base = use_lds ? reinterpret_cast<dd *>(smem_raw) : gscratch + (size_t)ce * 4 * kk;
-    dd *X = base, *T = base + kk, *O = base + 2 * kk, *W = base + 3 * kk;
+    dd *base = use_lds ? reinterpret_cast<dd *>(smem_raw) : gscratch + (size_t)ce * EXPM_BUFFERS * kk;
+    dd *X = base, *X2 = base + kk, *O = base + 2 * kk, *W = base + 3 * kk, *X3 = base + 4 * kk, *X4 = base + 5 * kk;
 
     const dd s = dd_two_prod(cat_rates[c], edge_rates[e]);
     for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
@@ -292,25 +297,32 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
         int sq = 0;
         while (norm > 0.03125) { norm *= 0.5; sq++; }
         s_sq = sq;
+        dd cn = dd_make(1.0, 0.0);
+        s_coef[0] = cn;
+        for (int n = 1; n <= EXPM_TERMS; n++) { cn = dd_div_d(cn, (double)n); s_coef[n] = cn; }
     }
     __syncthreads();
     const int sq = s_sq;
-    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
-        dd x = dd_ldexp(X[idx], -sq);
-        X[idx] = x;
-        T[idx] = x;
-        int i = idx / k, j = idx - i * k;
-        O[idx] = (i == j) ? dd_add_d(x, 1.0) : x;
-    }
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_ldexp(X[idx], -sq);
     __syncthreads();
-    for (int n = 2; n <= EXPM_TERMS; n++) {
-        dd_matmul_block(k, T, X, W);
+    dd_matmul_block(k, X, X, X2);
+    __syncthreads();
+    dd_matmul_block(k, X2, X, X3);
+    dd_matmul_block(k, X2, X2, X4);
+    __syncthreads();
+    /* cubic block i of the polynomial at entry idx */
+    auto block = [&](int ib, int idx) -> dd {
+        const int i = idx / k, j = idx - i * k;
+        dd v = dd_add(dd_mul(s_coef[4 * ib + 1], X[idx]), dd_add(dd_mul(s_coef[4 * ib + 2], X2[idx]), dd_mul(s_coef[4 * ib + 3], X3[idx])));
+        if (i == j) v = dd_add(v, s_coef[4 * ib]);
+        return v;
+    };
+    for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = dd_add(block(3, idx), dd_mul(s_coef[16], X4[idx]));
+    __syncthreads();
+    for (int ib = 2; ib >= 0; ib--) {
+        dd_matmul_block(k, X4, O, W);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
-            dd t = dd_div_d(W[idx], (double)n);
-            T[idx] = t;
-            O[idx] = dd_add(O[idx], t);
-        }
+        for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = dd_add(block(ib, idx), W[idx]);
         __syncthreads();
     }
     for (int q = 0; q < sq; q++) {
@@ -1200,9 +1212,9 @@ static int run_expm(plk_engine *h, bool post = false)
     if ((rc = dev_reserve(h, &h->d_Pdd, &h->pdd_cap, n))) return rc;
     if ((rc = dev_reserve(h, &h->d_P, &h->p_cap, n))) return rc;
     if ((rc = dev_reserve(h, &h->d_dP, &h->dp_cap, n))) return rc;
-    const size_t lds_bytes = 4 * kk * sizeof(dd);
+    const size_t lds_bytes = EXPM_BUFFERS * kk * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * 4 * kk))) return rc; }
+    if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * EXPM_BUFFERS * kk))) return rc; }
     /* one thread per few matrix entries: the dd matrix products are the whole cost for k = 61 */
     const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
     ExpmPost ep = {};
@@ -2413,12 +2425,12 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
     const int per_pass = use_updown4(h) && !use_mfma(h) ? 4 : 1;
     /* grow-only engine buffers: no per-call hipMalloc / hipFree */
     auto cleanup = [&]() {};
-    const size_t lds_bytes = 4 * n2 * sizeof(dd);
+    const size_t lds_bytes = EXPM_BUFFERS * n2 * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
     if ((rc = dev_reserve(h, &h->d_exL, &h->exL_cap, (size_t)per_pass * 2 * kk)) ||
         (rc = dev_reserve(h, &h->d_exF, &h->exF_cap, (size_t)per_pass * C * E * kk)) ||
         (rc = dev_reserve(h, &h->d_exmask, &h->exmask_cap, (size_t)E)) ||
-        (!use_lds && (rc = dev_reserve(h, &h->d_exscr, &h->exscr_cap, (size_t)C * E * 4 * n2)))) return rc;
+        (!use_lds && (rc = dev_reserve(h, &h->d_exscr, &h->exscr_cap, (size_t)C * E * EXPM_BUFFERS * n2)))) return rc;
     double *d_L = h->d_exL, *d_F = h->d_exF;
     int *d_mask = nullptr;
     dd *d_scr = h->d_exscr;
@@ -2490,9 +2502,9 @@ extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const
         if (d_scr) (void)hipFree(d_scr);
     };
     if ((rc = dev_upload(h, &d_L, L.data(), L.size())) || (rc = dev_alloc(h, &d_F, (size_t)C * E * kk))) { cleanup(); return rc; }
-    const size_t lds_bytes = 4 * n2 * sizeof(dd);
+    const size_t lds_bytes = EXPM_BUFFERS * n2 * sizeof(dd);
     const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * 4 * n2))) { cleanup(); return rc; }
+    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * EXPM_BUFFERS * n2))) { cleanup(); return rc; }
     const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
     hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
