@@ -2,16 +2,24 @@
 """
 bench.py -- sites/sec of the arbplf-ll hot path on MI355X (BASELINE.json metric).
 
-One "step" = one full pass of the ll path over the rank's resident site
-patterns: exp(Q r t) for every (category, edge) (K1, which for k = 4 also
-writes the matrix stream and the tip tables), the pruning kernel over all
-sites with category mixing and log (K2+K3), the weighted site reduction (K7)
-and, for N > 1, one RCCL all-reduce of the double-double log-likelihood sum
-(X1).  Pattern codes are resident in HBM before the timed region.  Steps are
-queued on the framework's stream (plk_ll_async): the {hi, lo} sum stays in
-device memory, the all-reduce works on it there, and the host reads the last
-sum after the timed region; the traversal kernel's time is taken from HIP
-events on that same stream around every launch of the timed region.
+One "step" = one full pass of the ll path over the site patterns: exp(Q r t)
+for every (category, edge) (K1, which for k = 4 also writes the matrix stream
+and the tip tables), the pruning kernel over all sites with category mixing and
+log (K2+K3), the weighted site reduction (K7) and, for N > 1, one RCCL
+all-reduce of the double-double log-likelihood sum (X1).  Pattern codes are
+resident in HBM before the timed region.  Steps are queued on the framework's
+stream (plk_ll_async): the {hi, lo} sum stays in device memory, the all-reduce
+works on it there, and the host reads the last sum after the timed region; the
+traversal kernel's time is taken from HIP events on that same stream around
+every launch of the timed region.
+
+Site sharding (the reference's only cross-site step is the axis
+reduction of src/ndaccum.c:198-254 after the site loop of src/arbplfll.c:139-170):
+  --scaling strong (default)  the metric's own split: the config's S sites (10M at
+      config 3; --sites overrides the TOTAL) are cut into shard.shard_range blocks,
+      one per rank; `value` = total sites x steps / time.
+  --scaling weak              every rank holds --sites patterns (its block of an
+      N x --sites alignment).
 
 After the ll region a short edge-gradient leg (arbplf-deriv: down + up pass,
 site-summed, 2E doubles all-reduced for N > 1) is timed and reported under
@@ -19,11 +27,11 @@ site-summed, 2E doubles all-reduced for N > 1) is timed and reported under
 
 Launch: `python bench.py` (1 GPU) or
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
-Sites are sharded by contiguous blocks, one process per GPU, weak scaling
-(every rank holds --sites patterns of the same synthetic alignment).
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -36,12 +44,95 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 FP64_PEAK = 78.6e12        # flop/s, fp64 vector = fp64 matrix dense peak
 
+# sources a kernel's measured HBM traffic depends on (profiles/traffic_*.json record their git blob hashes)
+KERNEL_SOURCES = {
+    "k_ll_fused4": ["plk_fused4_asm.h", "plk_fused4.h", "plk_program.h"],
+    "k_ll_vec": ["plk_vec.h", "plk_vec_matvec_asm.h"],
+    "k_ll_mfma": ["plk_mfma.h"],
+    "k_ll_generic": ["plk_engine.hip"],
+    "deriv4": ["plk_updown4.h", "plk_down4_asm.h"],
+    "deriv_vec": ["plk_updown_vec.h", "plk_vec_matvec_asm.h"],
+    "deriv_mfma": ["plk_mfma_updown.h"],
+}
+
+
+def git_blob_hash(path):
+    """the hash `git hash-object` prints for the file"""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes(key):
+    out = {}
+    for f in KERNEL_SOURCES.get(key, []):
+        p = os.path.join(ROOT, "phyly_amd", "csrc", f)
+        if os.path.exists(p):
+            out[f] = git_blob_hash(p)
+    return out
+
+
+def load_traffic(path, key, sites):
+    """HBM bytes per launch from a PMC file (tools/pmc_traffic.py), or None unless the file was measured at this site
+    count on exactly the kernel sources of this tree (git blob hashes recorded in the file)."""
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    if int(tj.get("sites", -1)) != int(sites):
+        return None
+    want = source_hashes(key)
+    if not want or tj.get("source_blobs") != want:
+        return None
+    return tj
+
+
+def host_cpu_share():
+    """threads this process may really use: min(affinity mask, cgroup CPU quota); plus what the box has"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    threads = aff if quota is None else max(1, min(aff, int(math.ceil(quota))))
+    phys = None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys_id = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys_id is not None and core_id is not None:
+                    cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        phys = len(cores) or None
+    except Exception:
+        pass
+    return dict(threads=threads, affinity=aff, cgroup_quota=quota, logical=os.cpu_count(), physical=phys)
+
 
 def cpu_baseline(workload, sample_sites, seconds=15.0):
-    """Oracle 'port' (oracle/plf_core.c, double build, OpenMP) on host cores."""
+    """Oracle 'port' (oracle/plf_core.c, double build, OpenMP) on the host cores this process is entitled to.
+    Only the C call is timed (inputs are contiguous arrays made before the clock starts)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import arbplf_oracle as O
     O.build()
+    share = host_cpu_share()
+    nt = share["threads"]
     codes0 = workload.simulate(256)
     md = workload.json_model(codes0[:, :1])
     m = O.parse_model(md)
@@ -49,26 +140,27 @@ def cpu_baseline(workload, sample_sites, seconds=15.0):
     # calibrate on a probe (second call: threads already started), then size the sample for ~`seconds`
     probe = min(sample_sites, 50000)
     codes = np.ascontiguousarray(workload.simulate(probe).T)
-    O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
+    O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0, nthreads=nt)
     t0 = time.perf_counter()
-    O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
+    O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0, nthreads=nt)
     dt = max(time.perf_counter() - t0, 1e-4)
     n = int(min(sample_sites, max(probe, probe * seconds / dt)))
     n = max(256, n // 256 * 256)
     reps = -(-n // probe)
     codes = np.ascontiguousarray(np.tile(codes, (reps, 1))[:n])   # the probe block repeated: same per-site work
-    t0 = time.perf_counter()
-    ll, used = O.site_ll(m, w, codes=codes, defs=workload.defs, precise=0)
-    dt = time.perf_counter() - t0
+    ll, used, dt = O.site_ll_timed(m, w, codes, workload.defs, precise=0, nthreads=nt)
     # the same port on ONE host thread, on a sample sized for a few seconds
     n1 = max(256, min(n, int(n * 4.0 / max(dt, 1e-3) / max(int(used), 1))) // 256 * 256)
-    t1 = time.perf_counter()
-    O.site_ll(m, w, codes=codes[:n1], defs=workload.defs, precise=0, nthreads=1)
-    dt1 = time.perf_counter() - t1
+    _, _, dt1 = O.site_ll_timed(m, w, codes[:n1], workload.defs, precise=0, nthreads=1)
+    # checker values for the bench's own cross-check: long double build on the first sites of the alignment
+    ncheck = min(probe, 4096)
+    ll_check, _ = O.site_ll(m, w, codes=codes[:ncheck], defs=workload.defs, precise=1, nthreads=nt)
     return dict(value=n / dt, unit="sites/s", cores=int(used), kind="port",
                 sample="%d sites (the first %d sites of the same synthetic alignment, repeated), double-precision "
-                       "oracle port, %d OpenMP threads, %.1f s" % (n, probe, used, dt),
-                one_thread=dict(value=n1 / dt1, unit="sites/s", cores=1, sample="%d sites, %.1f s" % (n1, dt1))), ll
+                       "oracle port, %d OpenMP threads, %.1f s in the C call" % (n, probe, used, dt),
+                host=share,
+                one_thread=dict(value=n1 / dt1, unit="sites/s", cores=1, sample="%d sites, %.1f s" % (n1, dt1)),
+                parallel_efficiency=(n / dt) / (n1 / dt1) / max(int(used), 1)), ll_check
 
 
 def main():
@@ -77,7 +169,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (2..5)")
-    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default: the config's S)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--sites", type=int, default=0, help="strong: total sites of the job (default: the config's S); weak: sites per GPU")
     ap.add_argument("--kernel", choices=["auto", "generic"], default="auto")
     ap.add_argument("--fused-ns", type=int, default=0, help="sites per lane of the fused kernel (0 = auto)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="ID=VALUE",
@@ -86,13 +179,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
     ap.add_argument("--deriv-steps", type=int, default=3, help="steps of the edge-gradient leg (0 = skip)")
-    ap.add_argument("--deriv-sites", type=int, default=0, help="sites of the edge-gradient leg (default: min(sites, 2M))")
+    ap.add_argument("--deriv-sites", type=int, default=0, help="sites per GPU of the edge-gradient leg (default: min(block, 2M))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from phyly_amd import synth
+    from phyly_amd import synth, shard
     from phyly_amd import engine as E
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +205,16 @@ def main():
     if args.categories and wl.mixture is not None:
         wl.mixture = dict(wl.mixture, gamma_categories=args.categories)
         wl.name += " [categories overridden: %d]" % args.categories
-    S = args.sites or wl.default_S
+    if args.scaling == "strong":
+        S_total = args.sites or wl.default_S
+        if S_total < world:
+            raise SystemExit("bench.py: fewer sites than ranks")
+        s0, s1 = shard.shard_range(S_total, rank, world)
+    else:
+        per = args.sites or wl.default_S
+        S_total = per * world
+        s0, s1 = rank * per, (rank + 1) * per
+    S = s1 - s0                                            # this rank's block [s0, s1) of the alignment
     eng = E.Engine(local_rank)
     wl.setup_engine(eng)
     if args.kernel == "generic":
@@ -128,7 +230,7 @@ def main():
     codes = torch.empty((wl.N, S), dtype=torch.uint8, device=dev)
     for off in range(0, S, chunk):
         n = min(chunk, S - off)
-        codes[:, off:off + n] = wl.simulate(n, site0=rank * S + off, device=dev)
+        codes[:, off:off + n] = wl.simulate(n, site0=s0 + off, device=dev)
     torch.cuda.synchronize()
     eng.set_patterns_codes(codes.data_ptr(), wl.defs, S=S, where=E.DEVICE)
     del codes
@@ -168,16 +270,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # edge-gradient leg: arbplf-deriv on a block of the same sites (site-summed gradient, reduced across ranks)
+    # per-site values of the first sites of rank 0's block, for the cross-check against the CPU checker below
+    ncheck = min(S, 4096)
+    gpu_ll_head = None
+    if rank == 0:
+        site_ll = torch.empty(S, dtype=torch.float64, device=dev)
+        eng.ll(out_device_ptr=site_ll.data_ptr(), want_sum=False)
+        gpu_ll_head = site_ll[:ncheck].cpu().numpy()
+        del site_ll
+
+    # edge-gradient leg: arbplf-deriv on the head of this rank's block (site-summed gradient, reduced across ranks)
     deriv_out = None
     if args.deriv_steps > 0:
-        from phyly_amd import shard
-        Sd = args.deriv_sites or min(S, 2_000_000)
+        Sd = min(S, args.deriv_sites or 2_000_000)
         if Sd != S:
             cd = torch.empty((wl.N, Sd), dtype=torch.uint8, device=dev)
             for off in range(0, Sd, chunk):
                 n = min(chunk, Sd - off)
-                cd[:, off:off + n] = wl.simulate(n, site0=rank * S + off, device=dev)
+                cd[:, off:off + n] = wl.simulate(n, site0=s0 + off, device=dev)
             torch.cuda.synchronize()
             eng.set_patterns_codes(cd.data_ptr(), wl.defs, S=Sd, where=E.DEVICE)
             del cd
@@ -200,60 +310,63 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dd_t = float(tmax.item())
         alg_d = wl.algorithmic()
+        dkey = "deriv4" if wl.k == 4 else ("deriv_vec" if wl.k <= 20 else "deriv_mfma")
+        dtr = load_traffic(os.path.join(ROOT, "profiles", "traffic_cfg%d_deriv.json" % args.config), dkey, Sd)
         deriv_out = dict(value=world * Sd * args.deriv_steps / dd_t, unit="sites/s", sites_per_gpu=Sd, steps=args.deriv_steps,
                          ms_per_step=dd_t / args.deriv_steps * 1e3, grad_max=float(np.abs(np.asarray(grad)).max()),
                          hbm_model_bytes_per_site=alg_d["A_deriv"],
-                         hbm_model_frac=alg_d["A_deriv"] * Sd * args.deriv_steps / dd_t / HBM_PEAK,
-                         note="whole arbplf-deriv step (K1, tables, down pass, up pass, weighted site sums%s); "
-                              "A_deriv = 6(I-1)Ck*8 + N of SURVEY.md 8d against 8 TB/s" % (", all-reduce of 2E doubles" if use_dist else ""))
+                         hbm_model_equiv_frac=alg_d["A_deriv"] * Sd * args.deriv_steps / dd_t / HBM_PEAK,
+                         hbm_measured_bytes_per_step=dtr["hbm_bytes_per_launch"] if dtr else None,
+                         hbm_measured_frac=(dtr["hbm_bytes_per_launch"] / (dd_t / args.deriv_steps) / HBM_PEAK) if dtr else None,
+                         note="whole arbplf-deriv step (K1, tables, down pass, up pass, weighted site sums%s). hbm_measured_frac = PMC "
+                              "bytes of the down + up kernels (profiles/traffic_cfg%d_deriv.json, used only when it was measured on "
+                              "this tree's kernel sources) / step time / 8 TB/s: the utilisation figure.  hbm_model_equiv_frac "
+                              "prices SURVEY.md 8d's A_deriv = 6(I-1)Ck*8 + N (stored edge vectors) at the step time; the kernels "
+                              "recompute edge vectors instead of storing them, so it is an equivalent rate, not a utilisation"
+                              % (", all-reduce of 2E doubles" if use_dist else "", args.config))
 
     if rank == 0:
         alg = wl.algorithmic()
         kernel_kind = eng.info(E.INFO_LL_KERNEL)
         kern_s = kern_ns_sum / kern_count * 1e-9
-        value = world * S * args.steps / dt
+        value = S_total * args.steps / dt
         hbm_equiv = alg["A_ll"] * S / kern_s
         flops = alg["W_ll"] * S / kern_s
         kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
         if kernel_kind == 1:
             kname = {1: "k_ll_fused4_asm", 3: "k_ll_fused4"}.get(eng.info(E.INFO_LL_VARIANT), kname)
         # HBM bytes per launch from the PMC passes of the guide's recipe (profiles/traffic_cfgN.json, written by
-        # tools/pmc_traffic.py from rocprofv3 --pmc runs of this kernel).  Only used when the file was measured on the
-        # kernel that ran here, at this site count; anything else is reported as null rather than a stale number.
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_cfg%d.json" % args.config)
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if str(tj.get("kernel", "")).startswith(kname) and int(tj.get("sites", -1)) == S:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        hbm_model = dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=hbm_equiv / HBM_PEAK,
-                         note="A_ll=%d B/site of the HBM-resident-partials design (SURVEY.md 8d)" % alg["A_ll"])
-        # which roof binds the kernel that ran: the fused and the matrix-core kernels keep the
+        # tools/pmc_traffic.py from rocprofv3 --pmc runs of this kernel).  Only used when the file was measured at this
+        # site count on the kernel sources of this very tree (git blob hashes); anything else is null, not a stale number.
+        tkey = {1: "k_ll_fused4", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
+        tj = load_traffic(os.path.join(ROOT, "profiles", "traffic_cfg%d.json" % args.config), tkey, S)
+        traffic = tj.get("hbm_bytes_per_launch") if tj and str(tj.get("kernel", "")).startswith(kname) else None
+        hbm_model = dict(achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", equiv_ratio=hbm_equiv / HBM_PEAK,
+                         note="A_ll=%d B/site of the HBM-resident-partials design (SURVEY.md 8d) priced at the kernel time; "
+                              "an equivalent rate (the partial vectors never move through HBM), not a utilisation" % alg["A_ll"])
+        # which roof binds the kernel that ran: the fused, vector and matrix-core kernels keep the
         # partial vectors out of HBM (compulsory traffic N+8 B/site), so fp64 arithmetic binds them;
         # the generic vector kernel streams its stack slots through HBM.
         fp64_bound = kernel_kind in (1, 3, 4) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
         if fp64_bound:
-            roofline = dict(bound="fp64", achieved=flops / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
-                            frac=flops / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
-                            note="fp64 FMA roof: 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz, AMD's "
-                                 "public MI355X figure for fp64 vector and fp64 matrix alike (SURVEY.md 8d; "
-                                 "MI355X_MICROARCH.md lists no fp64 peak); achieved = algorithmic flops W_ll=%d/site x "
-                                 "sites / kernel time from HIP events over the %d timed launches; the kernel skips the "
-                                 "leaf-edge products through tip tables, so executed flops are about half of W_ll"
-                                 % (alg["W_ll"], kern_count),
-                            hbm_model_equiv=hbm_model)
             # executed work: internal edges are full products (k^2 multiplies + k(k-1) fused multiply-adds), a leaf costs
-            # one k-wide multiply by its table row; what the fp64 pipe really issued, against the same peak
+            # one k-wide multiply by its table row; what the fp64 pipe really issues, against the fp64 peak
             k_, T_, C_ = wl.k, wl.T, wl.prepare()["C"]
             kpad = k_ if kernel_kind != 3 else ((k_ + 15) // 16) * 16
             exec_flops = C_ * ((wl.E - T_) * (2 * kpad * kpad - kpad) + T_ * k_)
-            roofline["executed"] = dict(flops_per_site=exec_flops, achieved=exec_flops * S / kern_s / 1e12,
-                                        frac=exec_flops * S / kern_s / FP64_PEAK,
-                                        note="C x ((E - T) internal-edge products of 2k^2 - k flops (k padded to 16 rows on the "
-                                             "matrix cores) + T leaf multiplies of k flops); stack and rescaling work not counted")
+            roofline = dict(bound="fp64", achieved=exec_flops * S / kern_s / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
+                            frac=exec_flops * S / kern_s / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
+                            flops_per_site=exec_flops,
+                            note="EXECUTED fp64 work / kernel time / fp64 peak.  Executed flops per site = C x ((E - T) internal-edge "
+                                 "products of 2k^2 - k flops (k padded to 16 rows on the matrix cores) + T leaf multiplies of k flops); "
+                                 "leaf-edge products are table rows and are not counted, nor are stack and rescaling moves.  Peak 78.6 "
+                                 "TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz, AMD's public MI355X figure for fp64 "
+                                 "vector and matrix alike (MI355X_MICROARCH.md lists no fp64 peak).  Kernel time from HIP events "
+                                 "over the %d timed launches on the kernel's stream" % kern_count,
+                            algorithmic=dict(flops_per_site=alg["W_ll"], achieved=flops / 1e12, ratio=flops / FP64_PEAK,
+                                             note="SURVEY.md 8d's W_ll (a full product on every edge, leaf edges included) priced at "
+                                                  "the kernel time: an equivalent rate, may exceed the peak, not a utilisation"),
+                            hbm_model_equiv=hbm_model)
         else:
             roofline = dict(bound="hbm", achieved=hbm_equiv / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                             frac=hbm_equiv / HBM_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
@@ -261,20 +374,36 @@ def main():
         out = {
             "metric": "sites/sec (arbplf-ll)", "value": value, "unit": "sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config %d: %s, %d sites per GPU, site-sharded" % (args.config, wl.name, S),
-                       "sites_per_gpu": S, "states": wl.k, "categories": wl.prepare()["C"], "taxa": wl.T,
+            "config": {"workload": "BASELINE config %d: %s, %d sites in all, site-sharded in contiguous blocks" % (args.config, wl.name, S_total),
+                       "total_sites": S_total, "sites_per_gpu": S, "states": wl.k, "categories": wl.prepare()["C"], "taxa": wl.T,
                        "parallelism": "site-shard x%d" % world},
             "ll_sum": total,
+            "step_minus_kernel_ms": dt / args.steps * 1e3 - kern_s * 1e3,
             "roofline": roofline,
         }
         if deriv_out is not None:
             out["deriv"] = deriv_out
-        if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_ll = cpu_baseline(wl, min(2 * S, 20_000_000), args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        if not args.no_cpu_baseline:
+            if world == 1:
+                cb, cpu_ll = cpu_baseline(wl, min(2 * S, 20_000_000), args.cpu_seconds)
+                out["cpu_baseline"] = cb
+                out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            else:
+                # N > 1: no timed CPU leg, only the checker values for the cross-check (long double build, 4096 sites)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle import arbplf_oracle as O
+                from helpers import oracle_site_ll
+                cpu_ll = oracle_site_ll(O, wl, wl.simulate(ncheck))
+            # the bench checks its own result: GPU per-site ll of the first sites against the CPU checker
+            n = min(len(cpu_ll), len(gpu_ll_head))
+            err = float(np.max(np.abs(gpu_ll_head[:n] - cpu_ll[:n]) / np.maximum(1.0, np.abs(cpu_ll[:n]))))
+            out["check"] = dict(sites=n, max_rel_err=err, tol=1e-12,
+                                against="oracle (long double build) on the first %d sites of the alignment" % n)
+            if not err <= 1e-12:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: GPU per-site ll differs from the CPU checker (max rel err %g)" % err)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -517,6 +517,28 @@ def site_ll(m, w, B=None, codes=None, defs=None, precise=1, nthreads=0):
     return out, used
 
 
+def site_ll_timed(m, w, codes, defs, precise=0, nthreads=0):
+    """site_ll for compact codes with only the C call inside the clock (bench.py's cpu_baseline leg):
+    -> (ll, threads used, seconds).  The output array is touched before the clock starts."""
+    import time
+    lib = _lib()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    defs = np.ascontiguousarray(defs, dtype=np.float64)
+    S = codes.shape[0]
+    out = np.empty(S)
+    out.fill(0.0)
+    P = w["Pq"] if int(precise) == 2 else np.ascontiguousarray(w["P"])
+    args = (ctypes.c_int(m.N), ctypes.c_int(m.E), ctypes.c_int(m.k), ctypes.c_int(w["C"]),
+            _iptr(m.indptr), _iptr(m.indices), _iptr(m.preorder), _dptr(P), _dptr(w["cat_prior"]),
+            ctypes.c_int(m.root_mode), _dptr(w["root_w"]), ctypes.c_long(S), None,
+            codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dptr(defs),
+            ctypes.c_int(int(precise)), ctypes.c_int(nthreads), _dptr(out))
+    t0 = time.perf_counter()
+    used = lib.orc_ll(*args)
+    dt = time.perf_counter() - t0
+    return out, used, dt
+
+
 def site_deriv(m, w, B, edge_requested=None, nthreads=0, precise=2):
     lib = _lib()
     B = np.ascontiguousarray(B, dtype=np.float64)

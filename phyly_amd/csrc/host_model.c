@@ -63,9 +63,10 @@ static int parse_edges(host_model *m, const jval *edges)
 {
     if (!j_is_array(edges)) FAILF("error: edges: a list of [parent, child] pairs is required\n");
     const int E = (int)j_len(edges), N = E + 1;
-    /* documented deviation: the reference accepts an empty edge list as a tree of one node
-     * (parsemodel.c:230-231); the device engine needs at least one edge and says so here */
-    if (E == 0) FAILF("error: edges: the list is empty; a tree of a single node has no branch to evaluate and is not supported\n");
+    /* An empty edge list is rejected by the reference as well: node_count = edge_count + 1 = 1 (src/parsemodel.c:230-231)
+     * and node 0 then fails "is not an endpoint of any edge" (src/parsemodel.c:306-318), so there is no single-node
+     * tree to evaluate.  Same outcome here, said up front. */
+    if (E == 0) FAILF("error: edges: the list is empty: node 0 is not an endpoint of any edge\n");
     int rc = -1;
     int *indeg = calloc(N, sizeof(int)), *outdeg = calloc(N, sizeof(int));
     int *pa = malloc((E + 1) * sizeof(int)), *pb = malloc((E + 1) * sizeof(int));

@@ -42,14 +42,28 @@ def allreduce_dd(pairs, device=None):
     return (hi + lo).astype(np.float64)
 
 
-def sharded_sum(local_fn, S, rank, world, device=None):
+def sharded_sum(local_fn, S, rank, world, device=None, shape=None):
     """Evaluate local_fn(s0, s1) -> [..., 2] double-double partial sums on this rank's
-    block of sites and all-reduce them."""
+    block of sites and all-reduce them.  A rank whose block is empty (more ranks than
+    sites) contributes zeros: it learns the shape of the partials from the other ranks
+    (one MAX all-reduce of the dimensions), or from `shape` when given."""
+    import torch
+    import torch.distributed as dist
     s0, s1 = shard_range(S, rank, world)
-    if s1 > s0:
-        part = np.asarray(local_fn(s0, s1), dtype=np.float64)
-    else:
-        part = None
+    part = np.asarray(local_fn(s0, s1), dtype=np.float64) if s1 > s0 else None
+    if part is None and shape is not None:
+        part = np.zeros(tuple(shape), dtype=np.float64)
+    if dist.is_available() and dist.is_initialized() and shape is None:
+        dims = torch.zeros(8, dtype=torch.int64)
+        if part is not None:
+            dims[0] = part.ndim
+            dims[1:1 + part.ndim] = torch.tensor(part.shape, dtype=torch.int64)
+        if device is not None:
+            dims = dims.to(device)
+        dist.all_reduce(dims, op=dist.ReduceOp.MAX)
+        dims = dims.cpu().tolist()
+        if part is None:
+            part = np.zeros(tuple(int(d) for d in dims[1:1 + int(dims[0])]), dtype=np.float64)
     if part is None:
-        raise ValueError("sharded_sum: rank %d of %d has no sites (S=%d)" % (rank, world, S))
+        raise ValueError("sharded_sum: no rank has sites and no shape was given (S=%d)" % S)
     return allreduce_dd(part, device)

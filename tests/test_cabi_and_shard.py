@@ -132,3 +132,45 @@ def test_site_sharding_gloo_world2(tmp_path, oracle):
     ll, _ = oracle.site_ll(m, w, codes=np.ascontiguousarray(codes.T), defs=wl.defs)
     want = float(np.sum(ll.astype(np.longdouble) * (1.0 + 0.001 * np.arange(1001))))
     assert abs(got - want) <= 1e-13 * abs(want)
+
+
+_WORKER_EMPTY = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from phyly_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+S = 2
+
+def local(s0, s1):                       # [3][2] double-double partials of this block
+    x = np.arange(s0, s1, dtype=np.float64) + 1.0
+    return np.stack([[x.sum(), 1e-20 * len(x)], [(x * x).sum(), 0.0], [len(x), 0.0]])
+
+tot = shard.sharded_sum(local, S, rank, world)
+tot2 = shard.sharded_sum(local, S, rank, world, shape=(3, 2))
+if rank == world - 1:
+    print(json.dumps({"tot": tot.tolist(), "tot2": tot2.tolist(), "block": list(shard.shard_range(S, rank, world))}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rank_without_sites_contributes_zeros_gloo_world3(tmp_path):
+    """more ranks than sites (S = 2, three ranks): the empty rank takes part in the all-reduce with zeros"""
+    script = tmp_path / "worker_empty.py"
+    script.write_text(_WORKER_EMPTY % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    got = json.loads(outs[2][0].decode().strip().splitlines()[-1])
+    assert got["block"] == [2, 2]                                     # the reporting rank is the empty one
+    assert got["tot"] == [3.0, 5.0, 2.0] and got["tot2"] == got["tot"]

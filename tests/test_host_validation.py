@@ -351,12 +351,16 @@ def test_character_data_file_side_channel(validate, tmp_path):
     assert validate(bad) != 0
 
 
-def test_single_node_tree_is_rejected_with_a_diagnostic(validate, capfd):
-    """Documented deviation (DESIGN.md): `edges: []` is a one-node tree in the reference (parsemodel.c:230-231);
-    the engine requires an edge, and the host layer rejects the model up front instead of failing inside plk_set_tree."""
+def test_empty_edge_list_is_rejected_like_the_reference(validate, capfd, oracle):
+    """`edges: []` gives node_count = 1 in the reference (src/parsemodel.c:230-231) and is then REJECTED by its own
+    degree check, "node index 0 is not an endpoint of any edge" (src/parsemodel.c:306-318): the reference has no
+    single-node tree.  Product and oracle reject it the same way (exit status / RuntimeError)."""
     x = {"model_and_data": {"edges": [], "edge_rate_coefficients": [],
                             "rate_matrix": [[0, 1.0], [1.0, 0]],
                             "probability_array": [[[1, 0]]]},
          "site_reduction": {"aggregation": "sum"}}
     assert validate(x) != 0
-    assert "single node" in capfd.readouterr().err
+    assert "not an endpoint of any edge" in capfd.readouterr().err
+    import json
+    with pytest.raises(RuntimeError):
+        oracle.arbplf_ll(json.dumps(x))
