@@ -205,7 +205,9 @@ enum {
     PLK_INFO_LAST_LL_TOTAL_NS = 4,  /* HIP-event time of the last whole plk_ll device work */
     PLK_INFO_LL_KERNEL_NS_SUM = 5,  /* HIP-event time of the traversal kernels of all ll evaluations since this item was */
     PLK_INFO_LL_KERNEL_COUNT = 6,   /* last read, and their number (reading waits for queued evaluations, then resets) */
-    PLK_INFO_LL_VARIANT = 7         /* k = 4 tile kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter, 0 another kernel */
+    PLK_INFO_LL_VARIANT = 7,        /* k = 4 tile kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter,
+                                       5 assembly interpreter with pair tables, 6 the same with two sites per lane, 0 another kernel */
+    PLK_INFO_PAIR_TABLES = 8        /* two-leaf subtrees the last k = 4 evaluation read from tables */
 };
 
 /* force the generic (HBM-resident partials) traversal even where the fused
@@ -220,7 +222,13 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
                                bit 0 (1): matrix-core kernels, 21 <= k <= 64 or all of 9 <= k <= 64 under PLK_OPT_MFMA = 2
                                (k_up_nodes_mfma: fewer HBM bytes, same speed as measured in round 2).
                                Marginal queries always take the one-edge-at-a-time passes.  ARBPLF_UP_NODES in the
-                               environment sets the initial value. */ };
+                               environment sets the initial value. */,
+       PLK_OPT_PAIR_TABLES = 6 /* k = 4 trees within 4 stack slots and 16 character definitions: two-leaf subtrees as table
+                               look-ups, grid-stride tile loop, one workgroup per CU.  1 (default): the interpreter with
+                               two sites per lane (k_ll_fused4_v4) on 1536-site tiles, or 1024-site tiles when the
+                               tables leave less LDS, else one site per lane; 5 / 6: two sites per lane on 1024 / 1536
+                               sites; 2 / 3: one site per lane (k_ll_fused4_asm_pt) on 1024 / 512 sites; 0: the round-2
+                               interpreter over 256-site tiles, no pair tables */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

@@ -98,6 +98,14 @@ struct plk_engine {
     std::vector<int> &obs_nodes = pg.obs_nodes;      /* nodes whose codes the fused kernels stage */
     int &slots_needed = pg.slots_needed;
     PlkFused fu;                         /* fused k = 4 formats of the program */
+    PlkFusedPT fpt;                      /* ... and of the pair-table interpreter (k_ll_fused4_asm_pt) */
+    bool fmt_pt = false;                 /* the uploaded kind-1 formats are the pair-table ones */
+    unsigned *d_words_pt = nullptr;
+    PlkFusedV4 fv4;                      /* 64-bit ops of the two-sites-per-lane interpreter */
+    int pt_kind = 0, pt_tile_sites = 0;  /* 1: k_ll_fused4_asm_pt, 2: k_ll_fused4_v4; sites per tile of the uploaded formats */
+    unsigned v4_tip_base = 0;            /* LDS address of the table image = static LDS of the kernel */
+    int *d_row_nodes = nullptr, *d_tabs = nullptr;   /* [2][rows] staged-row nodes; [4][ntab] unit, edge, leaf edges of a pair */
+    int num_cus = 256;
     int2 *d_ops = nullptr;
     int4 *d_fops = nullptr;              /* fused-kernel program (C++ interpreter) */
     unsigned *d_words = nullptr;         /* fused-kernel program (assembly interpreter) */
@@ -127,7 +135,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
 };
 
@@ -426,6 +434,58 @@ __global__ void k_build_tip(int E, int ntips, int nchar, const int *__restrict__
     }
 }
 
+/* Tables of the pair-table interpreter (plk_fused4_asm.h: k_ll_fused4_asm_pt), one block per (table, category), from
+ * the unrounded P in double-double.  tab[4][ntab]: first unit | edge (leaf edge of a single table, edge above the cherry
+ * of a pair table, -1 pseudo) | pair: the two leaf edges, else -1.
+ *   single  out[code][i]         = (P_e defs[code])_i
+ *   pair    out[cb*nchar+cc][i]  = (P_a (P_b defs[cb] o P_c defs[cc]))_i    (src/evaluate_site_lhood.c:36-56 for a cherry)
+ *   pseudo  out[code][i]         = defs[code][i]
+ * A constant vector maps to itself exactly under a stochastic matrix, as the reference's shortcut does (src/util.c:276-283). */
+__global__ void k_build_tables_pt(int E, int ntab, int units, int nchar, const int *__restrict__ tab,
+                                  const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][4] */,
+                                  double *__restrict__ tip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int unit = tab[t], e = tab[ntab + t], eb = tab[2 * ntab + t], ec = tab[3 * ntab + t];
+    double *out = tip + ((size_t)c * units + unit) * nchar * 4;
+    auto leaf = [&](const dd *Pm, const double *d, dd (&v)[4]) {
+        if (d[0] == d[1] && d[0] == d[2] && d[0] == d[3]) { for (int i = 0; i < 4; i++) v[i] = dd_make(d[0], 0.0); return; }
+        for (int i = 0; i < 4; i++) {
+            dd acc = dd_make(0.0, 0.0);
+            for (int j = 0; j < 4; j++) acc = dd_add(acc, dd_mul_d(Pm[i * 4 + j], d[j]));
+            v[i] = acc;
+        }
+    };
+    if (eb < 0) {
+        const dd *Pm = Pdd + ((size_t)c * E + (e < 0 ? 0 : e)) * 16;
+        for (int code = threadIdx.x; code < nchar; code += blockDim.x) {
+            const double *d = defs + code * 4;
+            dd v[4];
+            if (e < 0) { for (int i = 0; i < 4; i++) out[code * 4 + i] = d[i]; continue; }
+            leaf(Pm, d, v);
+            for (int i = 0; i < 4; i++) out[code * 4 + i] = v[i].hi;
+        }
+        return;
+    }
+    const dd *Pa = Pdd + ((size_t)c * E + e) * 16, *Pb = Pdd + ((size_t)c * E + eb) * 16, *Pc = Pdd + ((size_t)c * E + ec) * 16;
+    for (int comb = threadIdx.x; comb < nchar * nchar; comb += blockDim.x) {
+        const int cb = comb / nchar, cc = comb - cb * nchar;
+        dd vb[4], vc[4], pr[4];
+        leaf(Pb, defs + cb * 4, vb);
+        leaf(Pc, defs + cc * 4, vc);
+        bool cst = true;
+        for (int j = 0; j < 4; j++) { pr[j] = dd_mul(vb[j], vc[j]); cst = cst && pr[j].hi == pr[0].hi && pr[j].lo == pr[0].lo; }
+        for (int i = 0; i < 4; i++) {
+            dd acc = pr[0];
+            if (!cst) {
+                acc = dd_make(0.0, 0.0);
+                for (int j = 0; j < 4; j++) acc = dd_add(acc, dd_mul(Pa[i * 4 + j], pr[j]));
+            }
+            out[comb * 4 + i] = acc.hi;
+        }
+    }
+}
+
 /* flags[n] bit 0: some site's code at node n is not an all-ones definition; bit 1: some code is >= nchar
  * (the kernels index LDS and the tip tables with the codes: an out-of-range code must never reach them) */
 __global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes, int nchar,
@@ -524,6 +584,7 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
 
 #include "plk_fused4.h"
 #include "plk_fused4_asm.h"
+#include "plk_fused4_v4.h"
 #include "plk_mfma.h"
 #include "plk_mfma_updown.h"
 #include "plk_vec.h"
@@ -1052,6 +1113,7 @@ extern "C" int plk_create(plk_engine **out, int device)
     }
     plk_engine *h = new plk_engine();
     h->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus; }
     /* ARBPLF_UP_NODES = 1: initial value of PLK_OPT_UP_NODES, so that the JSON drivers (which own their engines) can be
      * run with the node-visit up pass too: tests/test_gpu_differential.py compares the two */
     if (const char *v = getenv("ARBPLF_UP_NODES")) h->opt_up_nodes = atol(v);
@@ -1092,7 +1154,7 @@ extern "C" void plk_destroy(plk_engine *h)
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
                     h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_edge_slot, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
-                    h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_u4pack, h->d_u4tip, h->d_uvmat, h->d_stage, h->d_exL, h->d_exF, h->d_exmask, h->d_exscr, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
+                    h->d_words_pt, h->d_row_nodes, h->d_tabs, h->d_PS, h->d_tip, h->d_frag, h->d_root_wd, h->d_mops, h->d_u4pack, h->d_u4tip, h->d_uvmat, h->d_stage, h->d_exL, h->d_exF, h->d_exmask, h->d_exscr, h->d_slots, h->d_site_ll, h->d_partial, h->d_work};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1114,6 +1176,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_UP_NODES) { h->opt_up_nodes = value; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
+    if (option == PLK_OPT_PAIR_TABLES) { h->opt_pair_tables = value; h->fmt_dirty = true; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
 }
@@ -1152,6 +1215,7 @@ extern "C" int plk_get_info(plk_engine *h, int what, long *out)
     case PLK_INFO_LL_KERNEL_COUNT: *out = h->evk_count; h->evk_count = 0; return PLK_OK;
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
     case PLK_INFO_LL_VARIANT: *out = h->info_ll_variant; return PLK_OK;
+    case PLK_INFO_PAIR_TABLES: *out = h->fmt_pt && h->fmt_kind == 1 && !h->fmt_dirty ? h->fpt.npairs : 0; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
     case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
     case PLK_INFO_LAST_LL_KERNEL_NS: *out = h->info_ll_kernel_ns; return PLK_OK;
@@ -1222,11 +1286,18 @@ static int run_expm(plk_engine *h, bool post = false)
     if (post) {
         ep.edge_slot = h->d_edge_slot; ep.nmat1 = (int)h->mat_edge.size() + 1; ep.ntips1 = (int)h->tip_edge.size() + 1;
         ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip;
+        if (h->fmt_pt) { ep.nmat1 = (int)h->fpt.mat_edge.size() + 1; ep.ntips1 = h->fpt.units; }    /* no tip slots in edge_slot: tables below */
     }
     hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
                        h->d_scratch, use_lds, (const double *)nullptr, 0, (const int *)nullptr, (double *)nullptr, ep);
     HIPCHK(h, hipGetLastError());
+    if (post && h->fmt_pt) {
+        const int ntab = (int)h->fpt.tab_unit.size();
+        hipLaunchKernelGGL(k_build_tables_pt, dim3(ntab, C), dim3(64), 0, h->stream,
+                           E, ntab, h->fpt.units, h->nchar, h->d_tabs, h->d_Pdd, h->d_defs, h->d_tip);
+        HIPCHK(h, hipGetLastError());
+    }
     h->model_dirty = false;
     h->tables_dirty = !post;
     return PLK_OK;
@@ -1308,7 +1379,7 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
     if (S < 1 || !codes || nchar < 1 || nchar > 256 || !defs) { h->err = "plk_set_patterns_codes: bad arguments"; return PLK_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     const int k = h->k, K = h->K, N = h->N;
-    const long Spad = (S + 1023) / 1024 * 1024;
+    const long Spad = (S + 3071) / 3072 * 3072;      /* rows padded to a whole number of 1024- and 1536-site tiles */
     int rc;
     if ((rc = dev_alloc(h, &h->d_codes, (size_t)N * Spad))) return rc;
     HIPCHK(h, hipMemset(h->d_codes, 0, (size_t)N * Spad));
@@ -1432,6 +1503,41 @@ static bool fused_asm_fits(const plk_engine *h)
     return plk_fused_lds_bytes(h->pg, h->nchar, h->nchar <= 16 ? PLK_TILE / 2 : PLK_TILE) <= PLK_LDS_LIMIT;
 }
 
+/* pair-table interpreter (k_ll_fused4_asm_pt): trees within the 4-slot VGPR stack and at most 16 character definitions
+ * (the combined code of a cherry is one byte); as many cherries become tables as the two-workgroups-per-CU LDS budget
+ * takes.  Fills fpt; false when even the table-less image does not fit (the 256-site kernels take over). */
+/* PLK_OPT_PAIR_TABLES: which pair-table interpreter, how many sites per tile (candidates in order of preference) */
+static bool build_fused_pt(plk_engine *h)
+{
+    if (!h->opt_pair_tables || !h->opt_fused_asm || h->opt_fused_ns == 2 || h->slots_needed > 4 || h->nchar > 16) return false;
+    if (h->obs_nodes.empty()) return false;
+    struct Cand { int kind, tile; };
+    std::vector<Cand> cands;
+    switch (h->opt_pair_tables) {
+    case 2: cands = {{1, 1024}}; break;
+    case 3: cands = {{1, 512}}; break;
+    case 5: cands = {{2, 1024}}; break;
+    case 6: cands = {{2, 1536}}; break;
+    default: cands = {{2, 1536}, {2, 1024}, {1, 1024}, {1, 512}}; break;
+    }
+    for (const Cand &cd : cands) {
+        const long limit = (long)plk_pt_lds_limit(cd.tile);
+        int max_pairs = INT_MAX;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            plk_fused_pt_build(h->N, h->indptr.data(), h->indices.data(), h->pg, h->nchar, max_pairs, h->fpt);
+            const long bytes = (long)plk_fused_pt_lds_bytes(h->fpt, h->nchar, cd.tile);
+            if (bytes <= limit && h->fpt.units < 2048 && h->fpt.row_node.size() < 65536) { h->pt_kind = cd.kind; h->pt_tile_sites = cd.tile; return true; }
+            if (h->fpt.npairs == 0) break;
+            /* a cherry as a table costs nchar - 2 more units and one row less than its two leaves */
+            const long per_pair = (long)(h->nchar - 2) * h->nchar * 32 - cd.tile;
+            if (per_pair <= 0) break;                       /* tables only shrink the image: nothing to give back */
+            const long drop = (bytes - limit + per_pair - 1) / per_pair;
+            max_pairs = drop >= h->fpt.npairs ? 0 : h->fpt.npairs - (int)drop;
+        }
+    }
+    return false;
+}
+
 static bool use_fused(const plk_engine *h)
 {
     if (h->opt_force_generic) return false;
@@ -1450,7 +1556,38 @@ static int upload_formats(plk_engine *h, long kind)
     te.push_back(-1);                                /* pseudo slot: the raw definitions (internal nodes with data) */
     if ((rc = dev_upload(h, &h->d_tip_edge, te.data(), te.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_obs_nodes, h->obs_nodes.data(), h->obs_nodes.size()))) return rc;
-    if (kind == 1) {
+    h->fmt_pt = false;
+    if (kind == 1 && build_fused_pt(h)) {
+        /* pair-table interpreter: op words, staged-row nodes, table list; K1 writes the matrix stream itself, the tables
+         * are built from the unrounded P after it (k_build_tables_pt) */
+        const PlkFusedPT &f = h->fpt;
+        const int nrows = (int)f.row_node.size(), ntab = (int)f.tab_unit.size();
+        if (h->pt_kind == 2) {
+            /* the table image starts where the kernel's static LDS ends */
+            hipFuncAttributes fa;
+            const void *fn = h->pt_tile_sites == 1536 ? (const void *)k_ll_fused4_v4<768> : (const void *)k_ll_fused4_v4<512>;
+            HIPCHK(h, hipFuncGetAttributes(&fa, fn));
+            h->v4_tip_base = (unsigned)fa.sharedSizeBytes;
+            plk_fused_v4_words(f, h->nchar, h->pt_tile_sites, h->v4_tip_base, h->fv4);
+            if ((rc = dev_upload(h, &h->d_words_pt, h->fv4.words.data(), h->fv4.words.size()))) return rc;
+        } else if ((rc = dev_upload(h, &h->d_words_pt, f.words.data(), f.words.size()))) return rc;
+        std::vector<int> rn(f.row_node);
+        rn.insert(rn.end(), f.row_node2.begin(), f.row_node2.end());
+        if ((rc = dev_upload(h, &h->d_row_nodes, rn.data(), rn.size()))) return rc;
+        std::vector<int> tabs(f.tab_unit);
+        tabs.insert(tabs.end(), f.tab_edge.begin(), f.tab_edge.end());
+        tabs.insert(tabs.end(), f.tab_eb.begin(), f.tab_eb.end());
+        tabs.insert(tabs.end(), f.tab_ec.begin(), f.tab_ec.end());
+        if ((rc = dev_upload(h, &h->d_tabs, tabs.data(), tabs.size()))) return rc;
+        std::vector<int> em(2 * (size_t)h->E, -1);
+        for (size_t mi = 0; mi < f.mat_edge.size(); mi++) em[f.mat_edge[mi]] = (int)mi;
+        if ((rc = dev_upload(h, &h->d_edge_slot, em.data(), em.size()))) return rc;
+        if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * (f.mat_edge.size() + 1) * 16))) return rc;
+        if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * f.units * h->nchar * 4))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_PS, 0, (size_t)h->C * (f.mat_edge.size() + 1) * 16 * sizeof(double), h->stream));
+        (void)nrows; (void)ntab;
+        h->fmt_pt = true;
+    } else if (kind == 1) {
         /* int4 ops of the C++ interpreter, 32-bit op words of the assembly interpreter, compact matrix list */
         plk_fused_build(h->N, h->pg, h->fu);
         if ((rc = dev_upload(h, &h->d_fops, reinterpret_cast<const int4 *>(h->fu.fops.data()), h->fu.fops.size()))) return rc;
@@ -1604,7 +1741,41 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         const size_t lds = plk_fused_lds_bytes(h->pg, h->nchar, PLK_TILE * NS);
         const bool use_asm = fused_asm_fits(h);
         const int D = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : 16);
-        if (use_asm) {
+        if (h->fmt_pt) {
+            /* pair-table interpreter: one 1024-site workgroup per CU (or two of 512), every workgroup walks the tiles with a grid stride */
+            const PlkFusedPT &f = h->fpt;
+            const int tile = h->pt_tile_sites;
+            const int ntiles = (int)((S + tile - 1) / tile);
+            if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)ntiles + PLK_PARTIAL_OFF))) return rc; }
+            const size_t lds_pt = plk_fused_pt_lds_bytes(f, h->nchar, tile);
+            std::string bad = plk_fused_check_pt(h->N, h->indptr.data(), h->indices.data(), h->pg, f, h->nchar, tile, lds_pt);
+            if (bad.empty() && h->pt_kind == 2) bad = plk_fused_check_v4(f, h->fv4, h->nchar, tile, h->v4_tip_base, lds_pt);
+            if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+            FusedPTArgs pa;
+            pa.f = a;
+            pa.f.nmat = (int)f.mat_edge.size(); pa.f.ntips = f.units; pa.f.nobs = (int)f.row_node.size();
+            pa.f.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
+            pa.words = h->d_words_pt; pa.row_nodes = h->d_row_nodes; pa.nwords = (int)(h->pt_kind == 2 ? h->fv4.words.size() : f.words.size());
+            pa.first_unit = f.first_unit; pa.first_row = f.first_row; pa.second_row = f.second_row; pa.ntiles = ntiles;
+            pa.warm = 1;
+            h->info_ll_variant = 5;
+            if (h->pt_kind == 2) {
+                /* two sites per lane: one workgroup of tile / 2 lanes per CU */
+                FusedV4Args va;
+                va.pt = pa; va.first_y = h->fv4.first_y; va.first_z = h->fv4.first_z; va.second_z = h->fv4.second_z;
+                grid = (unsigned)std::min(ntiles, h->num_cus);
+                if (tile == 1536) hipLaunchKernelGGL(k_ll_fused4_v4<768>, dim3(grid), dim3(768), lds_pt, h->stream, va);
+                else hipLaunchKernelGGL(k_ll_fused4_v4<512>, dim3(grid), dim3(512), lds_pt, h->stream, va);
+                h->info_ll_variant = 6;
+            } else if (tile == 1024) {
+                grid = (unsigned)std::min(ntiles, h->num_cus);
+                hipLaunchKernelGGL(k_ll_fused4_asm_pt<1024>, dim3(grid), dim3(1024), lds_pt, h->stream, pa);
+            } else {
+                grid = (unsigned)std::min(ntiles, 2 * h->num_cus);
+                hipLaunchKernelGGL(k_ll_fused4_asm_pt<512>, dim3(grid), dim3(512), lds_pt, h->stream, pa);
+            }
+            grid = (unsigned)ntiles;                      /* one partial sum per tile */
+        } else if (use_asm) {
             FusedAsmArgs aa;
             aa.f = a; aa.words = h->d_words;
             aa.first_tip = h->fu.asm_first_tip; aa.first_row = h->fu.asm_first_row; aa.second_row = h->fu.asm_second_row;

@@ -11,7 +11,7 @@
  *
  * Program format (built by prepare_stream_asm in plk_engine.hip): 32-bit op words in
  * blocks of 8, fetched a whole block ahead with one s_load_dwordx8;
- *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 MATVEC + TIP_MUL in one word, 5 TIP_MUL without wait, 6 SCALE, 7 END, 8 + d PUSH to
+ *   bits 4:0 handler index (0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 TIP_MUL without wait, 4 MATVEC + TIP_MUL in one word (slots 4 and 5), 6 SCALE, 7 END, 8 + d PUSH to
  *   stack slot d, 16 + d POPMUL of slot d, 24 + d / 28 + d MATVEC followed by PUSH / POPMUL of slot d < 4 when the
  *   tree needs at most 4 slots), bits 15:5 field y, bits 31:16 field z
  *   MATVEC            x = P x; matrices are consumed in stream order, the next one is
@@ -90,6 +90,30 @@
     "v_mov_b64 v[" #C0 ":" #C1 "], v[28:29]\n\t"                                          \
     "v_mov_b64 v[" #E0 ":" #E1 "], v[30:31]\n\t"                                          \
     "s_setpc_b64 s[88:89]\n"
+/* MATVEC + PUSH with the product written straight into the stack slot: the last column's FMAs take the slot's
+ * registers as destination, no moves (the vector under construction is dead after a PUSH: the next subtree starts
+ * with a TIP_SET) */
+#define PLK_ASM_MV_VPUSH_D(A0, A1, B0, B1, C0, C1, E0, E1)                                \
+    PLK_H_ALIGN                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                    \
+        "v_mul_f64 v[32:33], s[36:37], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[34:35], s[38:39], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[36:37], s[40:41], v[24:25]\n\t"                                  \
+        "v_mul_f64 v[38:39], s[42:43], v[24:25]\n\t"                                  \
+        "v_fma_f64 v[32:33], s[44:45], v[26:27], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[46:47], v[26:27], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[48:49], v[26:27], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[50:51], v[26:27], v[38:39]\n\t"                        \
+        "v_fma_f64 v[32:33], s[52:53], v[28:29], v[32:33]\n\t"                        \
+        "v_fma_f64 v[34:35], s[54:55], v[28:29], v[34:35]\n\t"                        \
+        "v_fma_f64 v[36:37], s[56:57], v[28:29], v[36:37]\n\t"                        \
+        "v_fma_f64 v[38:39], s[58:59], v[28:29], v[38:39]\n\t"                        \
+        "v_fma_f64 v[" #A0 ":" #A1 "], s[60:61], v[30:31], v[32:33]\n\t"              \
+        "v_fma_f64 v[" #B0 ":" #B1 "], s[62:63], v[30:31], v[34:35]\n\t"              \
+        "v_fma_f64 v[" #C0 ":" #C1 "], s[64:65], v[30:31], v[36:37]\n\t"              \
+        "v_fma_f64 v[" #E0 ":" #E1 "], s[66:67], v[30:31], v[38:39]\n\t"              \
+        PLK_ASM_NEXT_MATRIX                                \
+    "s_setpc_b64 s[88:89]\n"
 #define PLK_ASM_MV_VPOP(A0, A1, B0, B1, C0, C1, E0, E1)                                   \
     PLK_H_ALIGN PLK_ASM_MATVEC_CORE                                                       \
     "v_mul_f64 v[24:25], v[24:25], v[" #A0 ":" #A1 "]\n\t"                                \
@@ -97,6 +121,11 @@
     "v_mul_f64 v[28:29], v[28:29], v[" #C0 ":" #C1 "]\n\t"                                \
     "v_mul_f64 v[30:31], v[30:31], v[" #E0 ":" #E1 "]\n\t"                                \
     "s_setpc_b64 s[88:89]\n"
+#define PLK_ASM_SLOTS_D4_PAIRS_D                                                                          \
+    PLK_ASM_MV_VPUSH_D(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_MV_VPUSH_D(62, 63, 64, 65, 66, 67, 68, 69)   \
+    PLK_ASM_MV_VPUSH_D(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_MV_VPUSH_D(78, 79, 80, 81, 82, 83, 84, 85)   \
+    PLK_ASM_MV_VPOP(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_MV_VPOP(62, 63, 64, 65, 66, 67, 68, 69)         \
+    PLK_ASM_MV_VPOP(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_MV_VPOP(78, 79, 80, 81, 82, 83, 84, 85)
 #define PLK_ASM_SLOTS_D4_PAIRS                                                                            \
     PLK_ASM_MV_VPUSH(54, 55, 56, 57, 58, 59, 60, 61) PLK_ASM_MV_VPUSH(62, 63, 64, 65, 66, 67, 68, 69)       \
     PLK_ASM_MV_VPUSH(70, 71, 72, 73, 74, 75, 76, 77) PLK_ASM_MV_VPUSH(78, 79, 80, 81, 82, 83, 84, 85)       \
@@ -137,6 +166,22 @@
     PLK_ASM_POP(32, 33, 34, 35, 36, 37, 38, 39) PLK_ASM_POP(40, 41, 42, 43, 44, 45, 46, 47)   \
     PLK_ASM_POP(48, 49, 50, 51, 52, 53, 54, 55) PLK_ASM_POP(56, 57, 58, 59, 60, 61, 62, 63)
 
+/* (timing experiments only, never in the product build: -DPLK_EXP_NOMAT keeps the first matrix for every product,
+ * -DPLK_EXP_NOLDS drops the tip-value and code reads; results are wrong, the instruction stream is otherwise the same) */
+#ifdef PLK_EXP_NOMAT
+#define PLK_ASM_NEXT_MATRIX "s_add_u32 s86, s86, 0x80\n\t" "s_addc_u32 s87, s87, 0\n\t"
+#else
+#define PLK_ASM_NEXT_MATRIX                                                           \
+        "s_add_u32 s86, s86, 0x80\n\t"                                                \
+        "s_addc_u32 s87, s87, 0\n\t"                                                  \
+        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
+        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"
+#endif
+#ifdef PLK_EXP_NOLDS
+#define PLK_ASM_TIPREADS(A)
+#else
+#define PLK_ASM_TIPREADS(A) A
+#endif
 /* x = M x in place with the current matrix of the stream, then request the next one */
 #define PLK_ASM_MATVEC_CORE                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                    \
@@ -156,10 +201,7 @@
         "v_fma_f64 v[26:27], s[62:63], v[30:31], v[34:35]\n\t"                        \
         "v_fma_f64 v[28:29], s[64:65], v[30:31], v[36:37]\n\t"                        \
         "v_fma_f64 v[30:31], s[66:67], v[30:31], v[38:39]\n\t"                        \
-        "s_add_u32 s86, s86, 0x80\n\t"                                                \
-        "s_addc_u32 s87, s87, 0\n\t"                                                  \
-        "s_load_dwordx16 s[36:51], s[86:87], 0x0\n\t"                                 \
-        "s_load_dwordx16 s[52:67], s[86:87], 0x40\n\t"
+        PLK_ASM_NEXT_MATRIX
 
 /* the tail of an observation handler: request the value of the next observation op and the code of the one after */
 #define PLK_ASM_TIPNEXT                                                               \
@@ -175,13 +217,32 @@
         "v_add_u32 v43, s97, v44\n\t"                                                 \
         "ds_read_u8 v41, v43\n\t"                                                     \
         "s_setpc_b64 s[88:89]\n"
+/* the same for the pair-table kernel (V = 1): every staged row holds one byte per site (a pattern code, or the combined
+ * code of a two-leaf subtree), so the code is the table index as it comes from LDS: one integer instruction less */
+#ifdef PLK_EXP_NOTIPSALU
+#define PLK_ASM_TIPSALU(A)
+#else
+#define PLK_ASM_TIPSALU(A) A
+#endif
+#define PLK_ASM_TIPNEXT_B                                                             \
+        PLK_ASM_TIPSALU("s_bfe_u32 s98, s96, 0xb0005\n\t")                            \
+        PLK_ASM_TIPSALU("s_mul_i32 s98, s98, s93\n\t")                                \
+        PLK_ASM_TIPSALU("s_add_u32 s98, s98, s92\n\t")                                \
+        PLK_ASM_TIPSALU("s_lshr_b32 s97, s96, 16\n\t")                                \
+        PLK_ASM_TIPSALU("s_mul_i32 s97, s97, s94\n\t")                                \
+        "v_lshl_add_u32 v40, v41, 5, s98\n\t"                                         \
+        PLK_ASM_TIPREADS("ds_read_b128 v[46:49], v40\n\t")                            \
+        PLK_ASM_TIPREADS("ds_read_b128 v[50:53], v40 offset:16\n\t")                  \
+        "v_add_u32 v43, s97, v44\n\t"                                                 \
+        PLK_ASM_TIPREADS("ds_read_u8 v41, v43\n\t")                                   \
+        "s_setpc_b64 s[88:89]\n"
 #define PLK_ASM_TIPMUL                                                                \
         "v_mul_f64 v[24:25], v[24:25], v[46:47]\n\t"                                  \
         "v_mul_f64 v[26:27], v[26:27], v[48:49]\n\t"                                  \
         "v_mul_f64 v[28:29], v[28:29], v[50:51]\n\t"                                  \
         "v_mul_f64 v[30:31], v[30:31], v[52:53]\n\t"
 
-#define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS, PAIR_SLOTS)                                        \
+#define PLK_ASM_PROGRAM(POP_SLOTS, PUSH_SLOTS, PAIR_SLOTS, TIPNEXT)                                        \
         /* ---- prologue: operands into the fixed registers ---- */                   \
         "v_mov_b32 v24, %[x0lo]\n\tv_mov_b32 v25, %[x0hi]\n\t"                        \
         "v_mov_b32 v26, %[x1lo]\n\tv_mov_b32 v27, %[x1hi]\n\t"                        \
@@ -234,30 +295,31 @@
         "v_mov_b64 v[26:27], v[48:49]\n\t"                                            \
         "v_mov_b64 v[28:29], v[50:51]\n\t"                                            \
         "v_mov_b64 v[30:31], v[52:53]\n\t"                                            \
-        PLK_ASM_TIPNEXT                                                               \
+        TIPNEXT                                                                       \
         PLK_H_ALIGN                                                                   \
         "s_waitcnt lgkmcnt(0)\n\t"                                                    \
         PLK_ASM_TIPMUL                                                                \
-        PLK_ASM_TIPNEXT                                                               \
+        TIPNEXT                                                                       \
         /* ---- 2 MATVEC: x = M x in place ---- */                                    \
         PLK_H_ALIGN                                                                   \
         PLK_ASM_MATVEC_CORE                                                           \
         "s_setpc_b64 s[88:89]\n"                                                      \
-        /* ---- 3 (+ the space of 4) MATVEC followed by TIP_MUL: one op word, one dispatch.  The product's wait covers
-         * the prefetched tip value, and the word carries the observation's fields ---- */ \
-        PLK_H_ALIGN                                                                   \
-        PLK_ASM_MATVEC_CORE                                                           \
-        PLK_ASM_TIPMUL                                                                \
-        PLK_ASM_TIPNEXT                                                               \
-        /* (the pair handler is between 256 and 512 bytes long, so the next 256-byte boundary is handler 5's) */ \
-        /* ---- 5 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which starts with a full \
+        /* ---- 3 = TIP_MUL whose prefetched value is known to have landed: a MATVEC (which starts with a full \
          * wait) ran since the value was requested, so no wait is needed here and the matrix load that MATVEC   \
          * left in flight stays in flight ---- */                                     \
         PLK_H_ALIGN                                                                   \
         PLK_ASM_TIPMUL                                                                \
-        PLK_ASM_TIPNEXT                                                               \
-        /* ---- 6 SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */ \
+        TIPNEXT                                                                       \
+        /* ---- 4 (+ the space of 5) MATVEC followed by TIP_MUL: one op word, one dispatch.  The product's wait covers
+         * the prefetched tip value, and the word carries the observation's fields.  The handler starts on a 512-byte
+         * boundary (slot 4) and may be up to 512 bytes long: the next handler is aligned to 512 bytes, so it is slot 6's
+         * whatever the length of this body ---- */ \
         PLK_H_ALIGN                                                                   \
+        PLK_ASM_MATVEC_CORE                                                           \
+        PLK_ASM_TIPMUL                                                                \
+        TIPNEXT                                                                       \
+        ".p2align 9\n"                                                                \
+        /* ---- 6 SCALE: exact 2^-e, e = biased exponent of the largest entry - 1022 ---- */ \
         "v_max_u32 v43, v25, v27\n\t"                                                 \
         "v_max3_u32 v43, v29, v31, v43\n\t"                                           \
         "v_lshrrev_b32 v43, 20, v43\n\t"                                              \
@@ -319,17 +381,23 @@ struct FusedAsmParams {
 };
 
 /* Runs the whole program of one category for this lane's site: x = ones in, root vector out. */
-template <int D>
+/* V = 0: 4-bit / 8-bit codes extracted with v_bfe (k_ll_fused4_asm); V = 1: byte codes used as they are and MATVEC + PUSH
+ * written straight into the stack slot (k_ll_fused4_asm_pt, D = 4 only) */
+template <int D, int V = 0>
 __device__ __forceinline__ void fused_run_program_asm(double &x0, double &x1, double &x2, double &x3, int &esc,
                                                        const FusedAsmParams &p)
 {
     int x0lo = __double2loint(x0), x0hi = __double2hiint(x0), x1lo = __double2loint(x1), x1hi = __double2hiint(x1);
     int x2lo = __double2loint(x2), x2hi = __double2hiint(x2), x3lo = __double2loint(x3), x3hi = __double2hiint(x3);
-    if constexpr (D <= 4) {
-        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH, PLK_ASM_SLOTS_D4_PAIRS)
+    if constexpr (V == 1) {
+        static_assert(D <= 4, "the pair-table interpreter keeps its stack in VGPRs");
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH, PLK_ASM_SLOTS_D4_PAIRS_D, PLK_ASM_TIPNEXT_B)
+                     PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_V54_85);
+    } else if constexpr (D <= 4) {
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D4_POP, PLK_ASM_SLOTS_D4_PUSH, PLK_ASM_SLOTS_D4_PAIRS, PLK_ASM_TIPNEXT)
                      PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_V54_85);
     } else {
-        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH, PLK_ASM_SLOTS_D8_PAIRS)
+        asm volatile(PLK_ASM_PROGRAM(PLK_ASM_SLOTS_D8_POP, PLK_ASM_SLOTS_D8_PUSH, PLK_ASM_SLOTS_D8_PAIRS, PLK_ASM_TIPNEXT)
                      PLK_ASM_OPERANDS : PLK_ASM_CLOBBERS_COMMON, PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63);
     }
     x0 = __hiloint2double(x0hi, x0lo); x1 = __hiloint2double(x1hi, x1lo);
@@ -444,6 +512,174 @@ __global__ __launch_bounds__(PLK_TILE) void k_ll_fused4_asm(FusedAsmArgs aa)
     if (a.partial) {
         dd r = dd_block_sum(v);
         if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * k_ll_fused4_asm_pt: the same interpreter over 512-site tiles with PAIR TABLES (round 3).
+ *
+ * A node whose two children are both leaves (a "cherry") and that hangs on an edge contributes, per site, one of
+ * nchar^2 possible vectors P_a (P_b B_b o P_c B_c) -- the reference evaluates it by two _prune_update_prob calls and
+ * one product per site (src/evaluate_site_lhood.c:36-56).  Here K1 tabulates those vectors once per (category,
+ * cherry) in double-double (k_build_pair_tables), the staging step combines the two leaves' pattern codes into one
+ * byte, and the cherry becomes a single table look-up in the program: TIP_SET, TIP_MUL and the MATVEC of the edge
+ * above are one observation op.  At BASELINE config 3 that removes 33 of the 98 products and 66 of the 100 leaf
+ * multiplies per category.  A pair table takes nchar ordinary tip slots ("units" of nchar * 32 bytes); every staged
+ * row is one byte per site.  One workgroup of 1024 lanes per CU (4 waves per SIMD) shares one table image -- all waves
+ * of a CU are then in the same rate category, whose matrix stream fits the scalar cache -- and the workgroups walk the
+ * tiles with a grid stride: every CU gets the same number of tiles to within one.  (TILE = 512: two workgroups per CU.)
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* one dword of every 64-byte line of [base + first, base + bytes) at the given stride through the scalar cache, up to
+ * 12 requests in flight (the counter holds 15), all waited for before the statement ends */
+__device__ __forceinline__ void fused_touch_lines(const void *base, unsigned bytes, unsigned first, unsigned stride)
+{
+    unsigned off = first, batch;
+    asm volatile("s_cmp_ge_u32 %[off], %[end]\n\t"
+                 "s_cbranch_scc1 .Ltouch_done_%=\n"
+                 ".Ltouch_batch_%=:\n\t"
+                 "s_mov_b32 %[batch], 12\n"
+                 ".Ltouch_next_%=:\n\t"
+                 "s_load_dword s96, %[p], %[off]\n\t"
+                 "s_add_u32 %[off], %[off], %[stride]\n\t"
+                 "s_cmp_ge_u32 %[off], %[end]\n\t"
+                 "s_cbranch_scc1 .Ltouch_done_%=\n\t"
+                 "s_sub_u32 %[batch], %[batch], 1\n\t"
+                 "s_cmp_lg_u32 %[batch], 0\n\t"
+                 "s_cbranch_scc1 .Ltouch_next_%=\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_branch .Ltouch_batch_%=\n"
+                 ".Ltouch_done_%=:\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [off] "+s"(off), [batch] "=&s"(batch)
+                 : [p] "s"(base), [end] "s"(bytes), [stride] "s"(stride)
+                 : "s96", "scc", "memory");
+}
+
+struct FusedPTArgs {
+    FusedArgs f;                /* ntips = table units per category, nobs = staged rows; ops / obs_nodes / first_row unused */
+    const unsigned *words;      /* op words, blocks of 8, END padded, one spare block */
+    const int *row_nodes;       /* [2][nobs]: node of the row | second node of a pair row or -1 */
+    int first_unit, first_row, second_row;
+    int ntiles, nwords;
+    int warm;                   /* touch the category's matrix stream through the scalar cache before running the program */
+};
+
+template <int TILE>
+__global__ __launch_bounds__(TILE) void k_ll_fused4_asm_pt(FusedPTArgs aa)
+{
+    const FusedArgs &a = aa.f;
+    extern __shared__ double lds_dyn[];
+    double *tip_lds = lds_dyn;
+    const int tip_doubles = a.ntips * a.nchar * 4;
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_dyn + tip_doubles);
+    const int tid = threadIdx.x;
+    constexpr int NW = TILE / 64;         /* waves of the workgroup */
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PLK_AS4 int *rown = as_uniform(aa.row_nodes);
+    const PLK_AS4 double *prior = as_uniform(a.cat_prior);
+    const PLK_AS4 double *rootw = as_uniform(a.root_w);
+
+    FusedAsmParams p;
+    p.ops = aa.words;
+    p.tip_lds_addr = (unsigned)(size_t)tip_lds;
+    p.nchar32 = (unsigned)a.nchar * 32u;
+    p.row_bytes = TILE;
+    p.code_width = 8u;
+    p.first_tip_addr = p.tip_lds_addr + (unsigned)aa.first_unit * p.nchar32;
+    p.code_lane_addr = (unsigned)(size_t)code_lds + (unsigned)tid;
+    p.nibble_shift = 0u;
+    p.second_code_addr = p.code_lane_addr + (unsigned)aa.second_row * TILE;
+
+    for (int tile = blockIdx.x; tile < aa.ntiles; tile += gridDim.x) {
+        const long tile0 = (long)tile * TILE;
+        const long s = tile0 + tid;
+        __syncthreads();                 /* the previous tile's last category has been read */
+        /* staged rows: wave w takes rows w, w + 8, ...; a lane moves 8 codes of a row; four rows are requested before the
+         * first is stored.  A pair row holds code(b) * nchar + code(c): bytes do not carry into each other (nchar <= 16). */
+        for (int r0 = wave; r0 < a.nobs; r0 += 4 * NW) {
+            /* a lane moves TILE / 64 codes of a row: two (TILE = 512) or four (1024) dwords */
+            constexpr int ND = TILE / 256;
+            struct alignas(4 * ND) Chunk { unsigned d[ND]; };
+            Chunk q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = r0 + NW * u;
+#pragma unroll
+                for (int j = 0; j < ND; j++) q[u].d[j] = 0u;
+                if (row < a.nobs) {
+                    const int nb = rown[row], nc = rown[a.nobs + row];
+                    q[u] = reinterpret_cast<const Chunk *>(a.codes + (size_t)nb * a.Spad + tile0)[lane];
+                    if (nc >= 0) {
+                        const Chunk q2 = reinterpret_cast<const Chunk *>(a.codes + (size_t)nc * a.Spad + tile0)[lane];
+#pragma unroll
+                        for (int j = 0; j < ND; j++) q[u].d[j] = q[u].d[j] * (unsigned)a.nchar + q2.d[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = r0 + NW * u;
+                if (row < a.nobs) reinterpret_cast<Chunk *>(code_lds)[row * 64 + lane] = q[u];
+            }
+        }
+        double sum = 0.0;
+        int Eexp = 0;
+        bool have = false;
+        for (int c = 0; c < a.C; c++) {
+            __syncthreads();
+            {
+                /* Scalar-cache warm-up: the matrices of this category (nmat x 128 bytes, 8 KB at BASELINE config 3) and the op
+                 * words are what every wave of the workgroup fetches through the scalar cache, one matrix at a time and in step
+                 * with the other waves, so that a line missing in the 16 KB cache is waited for by all of them (44 % of the
+                 * requests of the round-2 kernel: profiles/r03_exp_headline_kernel_variants.json).  Here every wave touches a
+                 * slice of the lines, with all of its requests in flight at once, before the barrier below; the program then
+                 * runs on cache hits. */
+                if (aa.warm) {
+                    fused_touch_lines(a.PS + (size_t)c * (a.nmat + 1) * 16, (unsigned)(a.nmat + 1) * 128u, (unsigned)wave * 64u, NW * 64u);
+                    fused_touch_lines(aa.words, (unsigned)aa.nwords * 4u, (unsigned)wave * 64u, NW * 64u);
+                }
+            }
+            {
+                /* table image of the category: four 16-byte loads in flight per lane */
+                const double2 *src = reinterpret_cast<const double2 *>(a.tip + (size_t)c * tip_doubles);
+                double2 *dst = reinterpret_cast<double2 *>(tip_lds);
+                const int n2 = tip_doubles / 2;
+                for (int i0 = tid; i0 < n2; i0 += 4 * TILE) {
+                    double2 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = i0 + u * TILE < n2 ? src[i0 + u * TILE] : double2{0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (i0 + u * TILE < n2) dst[i0 + u * TILE] = v[u];
+                }
+            }
+            __syncthreads();
+            double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
+            int esc = 0;
+            p.mstream = a.PS + (size_t)c * (a.nmat + 1) * 16;
+            p.ch_first = code_lds[tid + aa.first_row * TILE];
+            fused_run_program_asm<4, 1>(x0, x1, x2, x3, esc, p);
+            double lh;
+            if (a.root_mode == PLK_ROOT_NONE) lh = ((x0 + x1) + x2) + x3;
+            else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((x0 + x1) + x2) + x3) * 0.25;
+            else lh = fma(rootw[3], x3, fma(rootw[2], x2, fma(rootw[1], x1, rootw[0] * x0)));
+            const double term = prior[c] * lh;
+            if (term != 0.0) {
+                if (!have) { sum = term; Eexp = esc; have = true; }
+                else if (esc > Eexp) { sum = ldexp(sum, Eexp - esc) + term; Eexp = esc; }
+                else sum += ldexp(term, esc - Eexp);
+            }
+        }
+        const double ll = have ? log(sum) + (double)Eexp * 0.6931471805599453094 : -INFINITY;
+        dd v = dd_make(0.0, 0.0);
+        if (s < a.S) {
+            if (a.site_ll) a.site_ll[s] = ll;
+            v = a.w ? dd_two_prod(a.w[s], ll) : dd_make(ll, 0.0);
+        }
+        if (a.partial) {
+            dd r = dd_block_sum(v);
+            if (tid == 0) a.partial[tile] = r;
+        }
     }
 }
 

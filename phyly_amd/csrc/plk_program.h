@@ -30,9 +30,9 @@ enum {
     OP_SCALE = 6,     /* cur *= 2^-e, exponent accumulated (exact)          */
     OP_END = 7
 };
-/* opcode 5 of the assembly interpreter's word format: TIP_MUL that may skip its wait (plk_fused4_asm.h) */
-#define PLK_WORD_TIPMUL_NOWAIT 5u
-#define PLK_WORD_MATVEC_TIPMUL 3u      /* assembly interpreter: MATVEC and the TIP_MUL that follows it, as one op word */
+/* handler 3 of the assembly interpreter's word format: TIP_MUL that may skip its wait (plk_fused4_asm.h) */
+#define PLK_WORD_TIPMUL_NOWAIT 3u
+#define PLK_WORD_MATVEC_TIPMUL 4u      /* assembly interpreter: MATVEC and the TIP_MUL that follows it, as one op word (handler slots 4 and 5) */
 
 struct plk_op2 { int x, y; };          /* layout of HIP's int2: x = opcode | tip_slot << 8, y = node / stack slot */
 struct plk_op4 { int x, y, z, w; };    /* layout of HIP's int4 */
@@ -387,11 +387,11 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
         for (int i = 0; i < 8; i++) {
             const size_t wi = b * 8 + i;
             const unsigned w = fu.words[wi];
-            /* the kernel jumps to handler (w & 31): 0..7 = opcode (3 = MATVEC + TIP_MUL, occupying the slots of 3 and 4),
+            /* the kernel jumps to handler (w & 31): 0..7 = opcode (3 = TIP_MUL without wait, 4 = MATVEC + TIP_MUL, occupying slots 4 and 5),
              * 8 + d = PUSH slot d, 16 + d = POPMUL slot d, 24 + d / 28 + d = MATVEC then PUSH / POPMUL slot d (4-slot
              * interpreter only) */
             const unsigned hidx = w & 31, z = w >> 16;
-            if (hidx == 4 || (hidx >= 24 && D != 4)) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)wi);
+            if (hidx == 5 || (hidx >= 24 && D != 4)) return plk_fmt("asm program: word %ld jumps to an empty handler slot", (long)wi);
             const unsigned y = hidx >= 24 ? (hidx & 3) : hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
             std::string bad;
             if (hidx == OP_END) {
@@ -415,6 +415,300 @@ static inline std::string plk_fused_check_asm(int N, const PlkProgram &pg, const
         }
         waited = true;                /* s_waitcnt lgkmcnt(0) at the end of every block */
     }
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* pair-table interpreter k_ll_fused4_asm_pt (plk_fused4_asm.h): 512-site tiles, byte rows, cherries as look-ups     */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* dynamic LDS the pair-table kernels may ask for, by sites per tile: one workgroup per CU (1024 sites on 1024 lanes, or
+ * 1024 / 1536 sites on 512 / 768 lanes with two sites each), or two 512-site workgroups */
+static inline size_t plk_pt_lds_limit(int tile) { return tile >= 1024 ? (size_t)156 * 1024 : (size_t)78 * 1024; }
+static inline bool plk_pt_tile_ok(int tile) { return tile == 512 || tile == 1024 || tile == 1536; }
+
+struct PlkFusedPT {
+    std::vector<unsigned> words;       /* blocks of 8, END padded, one spare block (format of PlkFused::words; the y field
+                                          counts table UNITS of nchar * 32 bytes) */
+    std::vector<int> mat_edge;         /* CSR edge per matrix of the stream (the kernel adds one spare) */
+    std::vector<int> row_node, row_node2;   /* staged rows: node | second node of a pair row or -1 */
+    /* tables of one category, in unit order: a single leaf (1 unit: P_e defs), a pair (nchar units:
+     * P_a (P_b defs[i] o P_c defs[j]) at code i * nchar + j) or the pseudo table (1 unit: the raw definitions) */
+    std::vector<int> tab_unit, tab_edge, tab_eb, tab_ec;   /* first unit | leaf edge, edge above the cherry or -1 | pair: leaf edges, else -1 */
+    int units = 0, npairs = 0;
+    int first_unit = 0, first_row = 0, second_row = 0;
+};
+
+/* the node whose CSR child range holds edge idx */
+static inline int plk_edge_parent(int N, const int *ip, int idx)
+{
+    int lo = 0, hi = N - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (ip[mid] <= idx) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+/* does the program continue at pc with TIP_SET(b), TIP_MUL(c), MATVEC(edge into a) for a node a whose only children
+ * are the leaves b and c? */
+static inline bool plk_pair_at(int N, const int *ip, const int *ix, const PlkProgram &pg, size_t pc)
+{
+    if (pc + 2 >= pg.ops.size()) return false;
+    if ((pg.ops[pc].x & 0xff) != OP_TIP_SET || (pg.ops[pc + 1].x & 0xff) != OP_TIP_MUL || (pg.ops[pc + 2].x & 0xff) != OP_MATVEC) return false;
+    const int eb = pg.op_edge[pc], ec = pg.op_edge[pc + 1], ea = pg.op_edge[pc + 2];
+    const int a = plk_edge_parent(N, ip, eb);
+    if (ip[a + 1] - ip[a] != 2 || plk_edge_parent(N, ip, ec) != a || eb == ec) return false;
+    return ea >= 0 && ix[ea] == a;
+}
+
+/* max_pairs: how many cherries may become tables (LDS budget); nchar * nchar <= 256 is the caller's business */
+static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const PlkProgram &pg, int nchar, int max_pairs, PlkFusedPT &fu)
+{
+    const int nops = (int)pg.ops.size();
+    struct VOp { int code, unit, row, d; };
+    std::vector<VOp> v;
+    fu.mat_edge.clear(); fu.row_node.clear(); fu.row_node2.clear();
+    fu.tab_unit.clear(); fu.tab_edge.clear(); fu.tab_eb.clear(); fu.tab_ec.clear();
+    fu.units = 0; fu.npairs = 0;
+    std::vector<int> row_of(N, -1);
+    auto single_row = [&](int node) {
+        if (row_of[node] < 0) { row_of[node] = (int)fu.row_node.size(); fu.row_node.push_back(node); fu.row_node2.push_back(-1); }
+        return row_of[node];
+    };
+    auto table = [&](int edge, int eb, int ec, int nunits) {
+        fu.tab_unit.push_back(fu.units); fu.tab_edge.push_back(edge); fu.tab_eb.push_back(eb); fu.tab_ec.push_back(ec);
+        const int u = fu.units; fu.units += nunits; return u;
+    };
+    int pseudo_unit = -1;
+    for (int pc = 0; pc < nops; pc++) {
+        const int code = pg.ops[pc].x & 0xff;
+        if (code == OP_TIP_SET && fu.npairs < max_pairs && plk_pair_at(N, ip, ix, pg, (size_t)pc)) {
+            const int row = (int)fu.row_node.size();
+            fu.row_node.push_back(pg.ops[pc].y); fu.row_node2.push_back(pg.ops[pc + 1].y);
+            v.push_back(VOp{OP_TIP_SET, table(pg.op_edge[pc + 2], pg.op_edge[pc], pg.op_edge[pc + 1], nchar), row, 0});
+            fu.npairs++;
+            pc += 2;
+        } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+            v.push_back(VOp{code, table(pg.op_edge[pc], -1, -1, 1), single_row(pg.ops[pc].y), 0});
+        } else if (code == OP_NODE_MUL) {
+            if (pseudo_unit < 0) pseudo_unit = table(-1, -1, -1, 1);
+            v.push_back(VOp{OP_TIP_MUL, pseudo_unit, single_row(pg.ops[pc].y), 0});
+        } else if (code == OP_MATVEC) {
+            fu.mat_edge.push_back(pg.op_edge[pc]);
+            v.push_back(VOp{OP_MATVEC, 0, 0, 0});
+        } else {
+            v.push_back(VOp{code, 0, 0, pg.ops[pc].y});
+        }
+    }
+    if (pseudo_unit < 0) table(-1, -1, -1, 1);      /* always present: keeps the image non-empty and the layout regular */
+    std::vector<int> ou, orow;
+    for (const VOp &o : v) if (o.code == OP_TIP_SET || o.code == OP_TIP_MUL) { ou.push_back(o.unit); orow.push_back(o.row); }
+    const int nv = (int)v.size();
+    fu.words.assign(((nv + 1 + 7) / 8) * 8 + 8, (unsigned)OP_END);
+    size_t oi = 0, nw = 0;
+    bool matvec_since_obs = false;
+    for (int i = 0; i < nv; i++) {
+        const int code = v[i].code;
+        unsigned wv = (unsigned)code;
+        auto obs_fields = [&]() {
+            /* cyclic: the last observations request the first ones again, so that every request of the chain pairs a
+             * table with a row of its own kind (the values are dropped; the next category's prologue asks again) */
+            const unsigned un = (unsigned)ou[(oi + 1) % ou.size()];
+            const unsigned rn = (unsigned)orow[(oi + 2) % orow.size()];
+            return (un << 5) | (rn << 16);
+        };
+        if (code == OP_MATVEC) {
+            const int nx = i + 1 < nv ? v[i + 1].code : OP_END;
+            if (nx == OP_TIP_MUL && oi > 0) {
+                fu.words[nw++] = PLK_WORD_MATVEC_TIPMUL | obs_fields();
+                oi++; matvec_since_obs = false; i++;
+                continue;
+            }
+            matvec_since_obs = true;
+            if ((nx == OP_PUSH || nx == OP_POPMUL) && pg.slots_needed <= 4) {
+                fu.words[nw++] = (nx == OP_PUSH ? 24u : 28u) + (unsigned)v[i + 1].d;
+                i++;
+                continue;
+            }
+        }
+        if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+            const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
+                                                   : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
+            wv = oc | obs_fields();
+            matvec_since_obs = false;
+            oi++;
+        } else if (code == OP_PUSH || code == OP_POPMUL) {
+            wv = (code == OP_PUSH ? 8u : 16u) + (unsigned)v[i].d;
+        }
+        fu.words[nw++] = wv;
+    }
+    fu.first_unit = ou.empty() ? 0 : ou[0];
+    fu.first_row = orow.empty() ? 0 : orow[0];
+    fu.second_row = orow.size() > 1 ? orow[1] : 0;
+}
+
+static inline size_t plk_fused_pt_lds_bytes(const PlkFusedPT &fu, int nchar, int tile)
+{
+    return (size_t)fu.units * nchar * 32 + fu.row_node.size() * (size_t)tile;
+}
+
+/*
+ * Replays k_ll_fused4_asm_pt on the host against the PROGRAM (not against the builder's intermediate list): block-ahead
+ * word fetch, matrix stream one ahead, LDS addresses of the value / code prefetch chain for the largest code of every
+ * table, field widths, stack slots; every observation word must deliver the table and the staged row of the program's
+ * next leaf op -- or, for a pair table, stand for exactly TIP_SET(b), TIP_MUL(c), MATVEC(edge above) of one cherry.
+ */
+static inline std::string plk_fused_check_pt(int N, const int *ip, const int *ix, const PlkProgram &pg, const PlkFusedPT &fu, int nchar,
+                                             int tile, size_t lds_bytes_launched)
+{
+    const int nops = (int)pg.ops.size(), nrows = (int)fu.row_node.size(), nmat = (int)fu.mat_edge.size(), ntab = (int)fu.tab_unit.size();
+    if (nchar < 1 || nchar > 16) return "pt program: pair tables need nchar <= 16";
+    if (pg.slots_needed > 4) return "pt program: the tree needs a deeper register stack";
+    if (fu.words.size() % 8 != 0 || fu.words.size() < 16) return "pt program: word buffer";
+    if ((int)fu.row_node2.size() != nrows || (int)fu.tab_edge.size() != ntab || (int)fu.tab_eb.size() != ntab || (int)fu.tab_ec.size() != ntab) return "pt program: table sizes";
+    const size_t tip_bytes = (size_t)fu.units * nchar * 32, code_bytes = (size_t)nrows * tile;
+    if (tip_bytes + code_bytes > lds_bytes_launched) return "pt program: LDS image larger than the launch's dynamic LDS";
+    if (!plk_pt_tile_ok(tile) || lds_bytes_launched > plk_pt_lds_limit(tile)) return "pt program: dynamic LDS above the limit";
+    if (nrows < 1 || fu.units < 1 || fu.units >= 2048 || nrows >= 65536) return "pt program: field widths";
+    for (int r = 0; r < nrows; r++)
+        if (fu.row_node[r] < 0 || fu.row_node[r] >= N || fu.row_node2[r] < -1 || fu.row_node2[r] >= N) return "pt program: staged row names a node out of range";
+    /* tables tile the unit range without gaps */
+    std::vector<int> table_at(fu.units, -1);
+    int expect = 0;
+    for (int t = 0; t < ntab; t++) {
+        const int nu = fu.tab_eb[t] >= 0 ? nchar : 1;
+        if (fu.tab_unit[t] != expect || expect + nu > fu.units) return "pt program: table layout";
+        table_at[expect] = t;
+        expect += nu;
+    }
+    if (expect != fu.units) return "pt program: table layout";
+    auto unit_ok = [&](long u) {
+        if (u < 0 || u >= fu.units || table_at[u] < 0) return false;
+        const long ncodes = fu.tab_eb[table_at[u]] >= 0 ? (long)nchar * nchar : nchar;
+        return (size_t)u * nchar * 32 + (size_t)ncodes * 32 <= tip_bytes;
+    };
+    auto row_ok = [&](long r) { return r >= 0 && r < nrows && (size_t)r * tile + (tile - 1) < code_bytes; };
+    if (!unit_ok(fu.first_unit) || !row_ok(fu.first_row) || !row_ok(fu.second_row)) return "pt program: prologue prefetch out of range";
+    if (fu.row_node2[fu.first_row] >= 0 && fu.tab_eb[table_at[fu.first_unit]] < 0) return "pt program: the prologue indexes a one-unit table with a pair row's code";
+    long cur_unit = fu.first_unit, cur_row = fu.first_row, next_row = fu.second_row;
+    int mi = 0;
+    bool waited = true, any_obs = false;
+    std::vector<char> full(4, 0), tab_used(ntab, 0);
+    const size_t nblocks = fu.words.size() / 8;
+    size_t pc = 0;
+    auto code_at = [&](size_t q) { return q < (size_t)nops ? (pg.ops[q].x & 0xff) : (int)OP_END; };
+    auto observation = [&](size_t wi, unsigned y, unsigned z, bool is_set, bool no_wait) -> std::string {
+        if (no_wait && !waited) return plk_fmt("pt program: word %ld skips a wait it needs", (long)wi);
+        if (!unit_ok(cur_unit) || !row_ok(cur_row)) return plk_fmt("pt program: word %ld consumes an observation out of range", (long)wi);
+        const int t = table_at[cur_unit];
+        if (tab_used[t]++ && fu.tab_edge[t] >= 0) return plk_fmt("pt program: table %ld used twice", (long)t);
+        const int code = code_at(pc);
+        if (fu.tab_eb[t] >= 0) {
+            /* a pair: the program must continue with the cherry's three ops */
+            if (!is_set || !plk_pair_at(N, ip, ix, pg, pc)) return plk_fmt("pt program: word %ld is a pair look-up where the program has no cherry", (long)wi);
+            if (fu.tab_eb[t] != pg.op_edge[pc] || fu.tab_ec[t] != pg.op_edge[pc + 1] || fu.tab_edge[t] != pg.op_edge[pc + 2]) return plk_fmt("pt program: pair table %ld holds other edges than the cherry at word %ld", (long)t, (long)wi);
+            if (fu.row_node[cur_row] != pg.ops[pc].y || fu.row_node2[cur_row] != pg.ops[pc + 1].y) return plk_fmt("pt program: pair row of word %ld", (long)wi);
+            pc += 3;
+        } else {
+            if (code != OP_TIP_SET && code != OP_TIP_MUL && code != OP_NODE_MUL) return plk_fmt("pt program: word %ld is not an observation op", (long)wi);
+            if (is_set != (code == OP_TIP_SET)) return plk_fmt("pt program: word %ld: SET/MUL mismatch", (long)wi);
+            if (fu.row_node[cur_row] != pg.ops[pc].y || fu.row_node2[cur_row] != -1) return plk_fmt("pt program: word %ld reads the wrong staged row", (long)wi);
+            if (fu.tab_edge[t] != (code == OP_NODE_MUL ? -1 : pg.op_edge[pc])) return plk_fmt("pt program: word %ld reads the wrong table", (long)wi);
+            pc++;
+        }
+        /* what the word requests: the value of the next observation = table y at the code that is in flight (row next_row),
+         * and the code of the observation after that (row z).  A pair row's codes reach nchar^2 - 1: only a pair table holds them. */
+        if (!unit_ok(y) || !row_ok(z) || !row_ok(next_row)) return plk_fmt("pt program: word %ld prefetches out of range (unit %ld, row %ld)", (long)wi, y, z);
+        if (fu.row_node2[next_row] >= 0 && fu.tab_eb[table_at[y]] < 0) return plk_fmt("pt program: word %ld indexes a one-unit table with a pair row's code", (long)wi);
+        cur_unit = y; cur_row = next_row; next_row = z;
+        waited = false; any_obs = true;
+        return "";
+    };
+    auto product = [&](size_t wi) -> std::string {
+        if (code_at(pc) != OP_MATVEC) return plk_fmt("pt program: word %ld is not the program's op", (long)wi);
+        if (mi >= nmat || fu.mat_edge[mi] != pg.op_edge[pc]) return plk_fmt("pt program: matrix %ld is not the op's edge", mi);
+        mi++; waited = true; pc++;
+        return "";
+    };
+    for (size_t b = 0;; b++) {
+        if (b + 1 >= nblocks) return "pt program: ran past the spare block (no END)";
+        for (int i = 0; i < 8; i++) {
+            const size_t wi = b * 8 + i;
+            const unsigned w = fu.words[wi];
+            const unsigned hidx = w & 31, z = w >> 16;
+            if (hidx == 5) return plk_fmt("pt program: word %ld jumps to an empty handler slot", (long)wi);
+            const unsigned y = hidx >= 24 ? (hidx & 3) : hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
+            std::string bad;
+            if (hidx == OP_END) {
+                if ((int)pc != nops) return plk_fmt("pt program: END at word %ld after %ld of the program's ops", (long)wi, (long)pc);
+                if (mi != nmat) return "pt program: matrix stream not consumed";
+                for (int t = 0; t < ntab; t++) if (fu.tab_edge[t] >= 0 && tab_used[t] != 1) return plk_fmt("pt program: table %ld is never read", (long)t);
+                (void)any_obs;
+                return "";
+            } else if (hidx == OP_MATVEC) bad = product(wi);
+            else if (hidx == PLK_WORD_MATVEC_TIPMUL) { bad = product(wi); if (bad.empty()) bad = observation(wi, y, z, false, true); }
+            else if (hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT) bad = observation(wi, y, z, hidx == OP_TIP_SET, hidx == PLK_WORD_TIPMUL_NOWAIT);
+            else if (hidx == OP_SCALE) { if (code_at(pc) != OP_SCALE) bad = plk_fmt("pt program: word %ld is not the program's op", (long)wi); pc++; }
+            else {
+                if (hidx >= 24) { bad = product(wi); if (!bad.empty()) return bad; }
+                const bool push = hidx >= 24 ? hidx < 28 : hidx < 16;
+                if (code_at(pc) != (push ? OP_PUSH : OP_POPMUL) || (int)y >= 4 || (int)y != pg.ops[pc].y || (full[y] != 0) == push)
+                    bad = plk_fmt(push ? "pt program: bad PUSH at word %ld" : "pt program: bad POPMUL at word %ld", (long)wi);
+                else full[y] = push;
+                pc++;
+            }
+            if (!bad.empty()) return bad;
+        }
+        waited = true;
+    }
+}
+
+/*
+ * 64-bit ops of the two-sites-per-lane interpreter k_ll_fused4_v4 (plk_fused4_v4.h), a re-encoding of PlkFusedPT::words:
+ *   lo = handler index * 512;  hi (observation ops) = (LDS offset / 32 of the next observation's table) << 16 |
+ *        (offset / 64 of the code row after next, relative to row 0);  tip_base = LDS byte address of the table image.
+ */
+#define PLK_V4_HANDLER_BYTES 512
+struct PlkFusedV4 {
+    std::vector<unsigned> words;       /* 2 dwords per op, blocks of 8 ops, the spare block included */
+    unsigned first_y = 0, first_z = 0, second_z = 0;
+};
+
+static inline bool plk_word_is_obs(unsigned hidx)
+{
+    return hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT || hidx == PLK_WORD_MATVEC_TIPMUL;
+}
+
+static inline void plk_fused_v4_words(const PlkFusedPT &fu, int nchar, int tile, unsigned tip_base, PlkFusedV4 &v4)
+{
+    const unsigned tb32 = tip_base / 32, rg = (unsigned)tile / 64;
+    v4.words.assign(fu.words.size() * 2, 0u);
+    for (size_t i = 0; i < fu.words.size(); i++) {
+        const unsigned w = fu.words[i], hidx = w & 31;
+        v4.words[2 * i] = hidx * PLK_V4_HANDLER_BYTES;
+        if (plk_word_is_obs(hidx)) v4.words[2 * i + 1] = ((tb32 + ((w >> 5) & 0x7ff) * (unsigned)nchar) << 16) | ((w >> 16) * rg);
+    }
+    v4.first_y = tb32 + (unsigned)fu.first_unit * (unsigned)nchar;
+    v4.first_z = (unsigned)fu.first_row * rg;
+    v4.second_z = (unsigned)fu.second_row * rg;
+}
+
+/* the 32-bit program is checked by plk_fused_check_pt; this checks the re-encoding: every field fits its 16 bits, is the
+ * 32-bit word's field times its granule, and the byte addresses the kernel forms from it stay inside the launch's LDS */
+static inline std::string plk_fused_check_v4(const PlkFusedPT &fu, const PlkFusedV4 &v4, int nchar, int tile, unsigned tip_base,
+                                             size_t lds_bytes_launched)
+{
+    if (tip_base % 32 != 0 || tile % 64 != 0) return "v4 program: LDS base or tile granule";
+    if (v4.words.size() != 2 * fu.words.size()) return "v4 program: word count";
+    const size_t tip_bytes = (size_t)fu.units * nchar * 32, lds_end = tip_base + lds_bytes_launched;
+    const unsigned tb32 = tip_base / 32, rg = (unsigned)tile / 64;
+    auto y_ok = [&](unsigned y, unsigned unit) { return y == tb32 + unit * (unsigned)nchar && y < 65536u && (size_t)y * 32 + (size_t)nchar * nchar * 32 <= lds_end + (size_t)nchar * nchar * 32 && (size_t)y * 32 >= tip_base && (size_t)y * 32 < tip_base + tip_bytes; };
+    auto z_ok = [&](unsigned z, unsigned row) { return z == row * rg && z < 65536u && tip_base + tip_bytes + (size_t)z * 64 + (size_t)tile <= lds_end; };
+    if (!y_ok(v4.first_y, (unsigned)fu.first_unit) || !z_ok(v4.first_z, (unsigned)fu.first_row) || !z_ok(v4.second_z, (unsigned)fu.second_row)) return "v4 program: prologue fields";
+    for (size_t i = 0; i < fu.words.size(); i++) {
+        const unsigned w = fu.words[i], hidx = w & 31, lo = v4.words[2 * i], hi = v4.words[2 * i + 1];
+        if (lo != hidx * PLK_V4_HANDLER_BYTES || lo >= 32u * PLK_V4_HANDLER_BYTES) return plk_fmt("v4 program: handler offset of op %ld", (long)i);
+        if (!plk_word_is_obs(hidx)) { if (hi != 0) return plk_fmt("v4 program: stray fields in op %ld", (long)i); continue; }
+        if (!y_ok(hi >> 16, (w >> 5) & 0x7ff) || !z_ok(hi & 0xffff, w >> 16)) return plk_fmt("v4 program: fields of op %ld", (long)i);
+    }
+    return "";
 }
 
 /* the C++ interpreter k_ll_fused4<D, NS> (plk_fused4.h): pair-ahead fetch, one-ahead code row chain */

@@ -169,6 +169,49 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
             if (plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: missing END accepted";
         }
     }
+    /* pair-table interpreter (k_ll_fused4_asm_pt): with every cherry as a table, with a budget of one, with none */
+    if (pg.slots_needed <= 4 && nchar <= 16 && !pg.obs_nodes.empty()) {
+        const int budgets[3] = {1 << 30, 1, 0};
+        for (int bi = 0; bi < 3; bi++) {
+            PlkFusedPT fp;
+            plk_fused_pt_build(N, t.ip.data(), t.ix.data(), pg, nchar, budgets[bi], fp);
+            if (fp.npairs > budgets[bi]) return "pt: more pair tables than the budget";
+            const int tile = (N + bi) % 2 ? 512 : 1024;
+            const size_t lds = plk_fused_pt_lds_bytes(fp, nchar, tile);
+            if (lds > plk_pt_lds_limit(tile) || fp.units >= 2048) continue;
+            bad = plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, fp, nchar, tile, lds);
+            if (!bad.empty()) return "pt budget " + std::to_string(bi) + ": " + bad;
+            /* every edge is either a matrix of the stream, the leaf edge of a one-unit table, or one of the three edges
+             * of a pair table -- exactly once */
+            std::vector<int> seen(E > 0 ? E : 1, 0);
+            for (int e : fp.mat_edge) seen[e]++;
+            for (size_t q = 0; q < fp.tab_edge.size(); q++) {
+                if (fp.tab_edge[q] >= 0) seen[fp.tab_edge[q]]++;
+                if (fp.tab_eb[q] >= 0) { seen[fp.tab_eb[q]]++; seen[fp.tab_ec[q]]++; }
+            }
+            for (int e = 0; e < E; e++) if (seen[e] != 1) return "pt: edge " + std::to_string(e) + " covered " + std::to_string(seen[e]) + " times";
+            if (bi != 0) continue;
+            /* negative controls */
+            if (plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, fp, nchar, tile, lds - 1).empty()) return "negative control (pt): short LDS accepted";
+            PlkFusedPT f2 = fp;
+            for (size_t w = 0; w < f2.words.size(); w++)
+                if ((f2.words[w] & 31) == OP_END) { f2.words[w] = OP_SCALE; break; }
+            if (plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, f2, nchar, tile, lds).empty()) return "negative control (pt): missing END accepted";
+            if (fp.npairs > 0) {
+                f2 = fp;
+                for (size_t q = 0; q < f2.tab_eb.size(); q++) if (f2.tab_eb[q] >= 0) { std::swap(f2.tab_eb[q], f2.tab_edge[q]); break; }
+                if (plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, f2, nchar, tile, lds).empty()) return "negative control (pt): pair table with swapped edges accepted";
+                f2 = fp;
+                for (size_t r = 0; r < f2.row_node2.size(); r++) if (f2.row_node2[r] >= 0) { f2.row_node2[r] = -1; break; }
+                if (plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, f2, nchar, tile, lds).empty()) return "negative control (pt): pair row without its second node accepted";
+            }
+            f2 = fp;
+            bool touched = false;
+            for (size_t w = 0; w < f2.words.size() && !touched; w++)
+                if ((f2.words[w] & 31) <= 1) { f2.words[w] = (f2.words[w] & 0xffff) | ((unsigned)fp.row_node.size() << 16); touched = true; }
+            if (touched && plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, f2, nchar, tile, lds).empty()) return "negative control (pt): row field out of range accepted";
+        }
+    }
     return "";
 }
 

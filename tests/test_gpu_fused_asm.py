@@ -19,17 +19,24 @@ def eng():
     e.close()
 
 
-def _both(eng, codes, defs, w=None):
-    """variant 1: assembly interpreter, 3: C++ interpreter (PLK_INFO_LL_VARIANT numbering)"""
+def _both(eng, codes, defs, w=None, pt=True):
+    """PLK_INFO_LL_VARIANT numbering: 6 pair-table interpreter with two sites per lane (the default where it applies;
+    PLK_OPT_PAIR_TABLES 1 = widest tile that fits, 5 = 1024-site tiles), 5 pair tables with one site per lane
+    (options 2, 3), 1 assembly interpreter over 256-site tiles (option 0), 3 C++ interpreter.
+    -> {(variant, option): (per-site ll, weighted sum)}"""
     out = {}
-    for variant, opt in ((1, 1), (3, 0)):
-        eng.set_option(E.OPT_FUSED_ASM, opt)
+    for variant, asm, pairs in ((6, 1, 1), (6, 1, 5), (5, 1, 2), (5, 1, 3), (1, 1, 0), (3, 0, 0)):
+        if variant >= 5 and not pt:
+            continue
+        eng.set_option(E.OPT_FUSED_ASM, asm)
+        eng.set_option(E.OPT_PAIR_TABLES, pairs)
         eng.set_patterns_codes(codes, defs)
         eng.set_site_weights(w)
         ll, s = eng.ll()
-        assert eng.info(E.INFO_LL_KERNEL) == 1 and eng.info(E.INFO_LL_VARIANT) == variant
-        out[variant] = (ll, s[0] + s[1])
+        assert eng.info(E.INFO_LL_KERNEL) == 1 and eng.info(E.INFO_LL_VARIANT) == variant, (variant, pairs, eng.info(E.INFO_LL_VARIANT))
+        out[(variant, pairs)] = (ll, s[0] + s[1])
     eng.set_option(E.OPT_FUSED_ASM, 1)
+    eng.set_option(E.OPT_PAIR_TABLES, 1)
     eng.set_site_weights(None)
     return out
 
@@ -45,11 +52,18 @@ def test_matches_oracle_and_cpp_interpreter(eng, oracle, T, S, cats):
     w = np.linspace(0.25, 1.75, S)
     out = _both(eng, codes, wl.defs, w)
     want = oracle_site_ll(oracle, wl, codes)
-    for variant in (1, 3):
-        ll, tot = out[variant]
-        assert np.max(np.abs(ll - want) / np.maximum(1.0, np.abs(want))) <= 1e-12
-        assert abs(tot - float(np.sum(want.astype(np.longdouble) * w))) <= 1e-12 * abs(tot)
-    assert np.max(np.abs(out[1][0] - out[3][0])) <= 1e-13 * np.max(np.abs(want))
+    for key, (ll, tot) in out.items():
+        assert np.max(np.abs(ll - want) / np.maximum(1.0, np.abs(want))) <= 1e-12, key
+        assert abs(tot - float(np.sum(want.astype(np.longdouble) * w))) <= 1e-12 * abs(tot), key
+    assert np.max(np.abs(out[(1, 0)][0] - out[(3, 0)][0])) <= 1e-13 * np.max(np.abs(want))
+    for key in out:
+        assert np.max(np.abs(out[key][0] - out[(1, 0)][0])) <= 1e-13 * np.max(np.abs(want)), key
+    assert np.array_equal(out[(6, 1)][0], out[(5, 2)][0])          # the same tables, the same arithmetic per site
+    if T >= 12:
+        assert eng.info(E.INFO_PAIR_TABLES) == 0          # the last evaluation ran without them
+        eng.set_patterns_codes(codes, wl.defs)
+        eng.ll()
+        assert eng.info(E.INFO_LL_VARIANT) == 6 and eng.info(E.INFO_PAIR_TABLES) >= 1
 
 
 def test_wide_codes_and_node_data(eng, oracle):
@@ -64,14 +78,14 @@ def test_wide_codes_and_node_data(eng, oracle):
     defs = np.vstack([wl.defs, extra])                      # 21 definitions
     amb = rng.random(codes.shape) < 0.15
     codes = np.where(amb, rng.integers(5, 21, size=codes.shape), codes).astype(np.uint8)
-    out = _both(eng, codes, defs)
+    out = _both(eng, codes, defs, pt=False)                 # 21 definitions: beyond the pair tables' 16
     md = wl.json_model(codes[:, :1])
     md["character_definitions"] = defs.tolist()
     m = oracle.parse_model(md)
     ow = oracle.prepare(m)
     want, _ = oracle.site_ll(m, ow, codes=np.ascontiguousarray(codes.T), defs=defs, precise=1)
-    for variant in (1, 3):
-        assert np.max(np.abs(out[variant][0] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12
+    for key in ((1, 0), (3, 0)):
+        assert np.max(np.abs(out[key][0] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12
 
 
 @pytest.mark.parametrize("T,variant", [(430, 1), (700, 0)])

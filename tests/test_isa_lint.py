@@ -100,12 +100,12 @@ def test_handler_table_layout_check_accepts_the_build_and_rejects_an_overlong_ha
     def table(overlong_slot):
         ins, a = [(0x1ffc, "s_nop")], 0x2000
         for slot in range(mod.NSLOTS):
-            n = 70 if slot == overlong_slot else (68 if slot == 3 else 10)     # 4-byte instructions: 70 > 64 per slot
+            n = 70 if slot == overlong_slot else (68 if slot == 4 else 10)     # 4-byte instructions: 70 > 64 per slot
             end = a + 4 * n
             while a < end - 4:
                 ins.append((a, "v_fma_f64")); a += 4
             ins.append((a, "s_setpc_b64")); a += 4
-            nxt = 0x2000 + 256 * (slot + 1) if slot != 3 else a               # slot 3 runs on into slot 4
+            nxt = 0x2000 + 256 * (slot + 1) if slot != 4 else a               # slot 4 runs on into slot 5
             while a < nxt:
                 ins.append((a, "s_nop")); a += 4
         ins.append((a, "s_waitcnt"))

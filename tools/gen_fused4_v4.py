@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generates phyly_amd/csrc/plk_fused4_v4_asm.h: the CDNA4 assembly text of the k = 4 pair-table interpreter with TWO
+sites per lane (k_ll_fused4_v4, plk_fused4_v4.h).
+
+Why a generator: every handler exists once per stack slot and every vector instruction twice (site A, site B,
+interleaved so that the two independent dependency chains alternate in the issue stream); written as C macros that is
+~700 lines of hand-numbered registers.  The register map, the handler numbering and the op-word format are defined
+here once and the header is emitted from them.  Run `python tools/gen_fused4_v4.py` after changing this file; the header
+is committed, the build does not depend on Python.
+
+Op format (built by plk_fused_v4_words in plk_program.h from the pair-table program): 64 bits per op, blocks of 8 ops,
+  lo dword  handler index * 512 (byte offset of the handler in the table; the table is 16 KB aligned)
+  hi dword  observation ops: bits 31:16 = LDS offset / 32 of the table the NEXT observation op reads, bits 15:0 = LDS
+            offset / 64 of the staged code row of the observation op AFTER the next (both relative to LDS address 0)
+Handler indices: 0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 TIP_MUL without wait, 4 MATVEC + TIP_MUL, 6 SCALE, 7 END,
+8 + d PUSH slot d, 16 + d POPMUL slot d, 24 + d MATVEC + PUSH slot d, 28 + d MATVEC + POPMUL slot d (d < 4).
+
+Registers (all named in the clobber list of the asm statement):
+  v[24:31] xA  v[32:39] xB   vectors under construction (site A = lane's first site, site B = HALF sites further)
+  v[40:47] tA  v[48:55] tB   product accumulators
+  v[56:63] pA  v[64:71] pB   prefetched tip / pair-table value of the next observation op
+  v72 v73 value addresses   v74 v75 code bytes of the next observation op   v76 code address   v77 LDS address of the
+  lane's byte in row 0 (site A; site B at +HALF)   v78 v79 scale exponents   v80 v81 temporaries
+  v[82:145] stack: slot d = A v[82+16d : 89+16d], B v[90+16d : 97+16d]
+  s[36:67] current matrix (transposed)   s[68:83] op block in use   s[20:35] the other op block
+  s[84:85] program pointer   s[86:87] matrix stream pointer   s[88:89] return address   s[90:91] handler table
+  s95 = -1022   s96 hi dword of the op   s97 s98 temporaries   s99 = s91
+"""
+import os
+
+HS = 512                      # bytes per handler slot
+XA, XB, TA, TB, PA, PB = 24, 32, 40, 48, 56, 64
+STACK0 = 82
+
+
+def pair(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def slot_regs(d, site):
+    base = STACK0 + 16 * d + 8 * site
+    return [base + 2 * i for i in range(4)]
+
+
+def matvec(dst_a=None, dst_b=None):
+    """x = M x for both sites, rows interleaved A/B; dst_*: registers of the result (default in place)"""
+    out = ["s_waitcnt lgkmcnt(0)"]
+    for col in range(4):
+        for row in range(4):
+            s = 36 + 8 * col + 2 * row
+            for (x, t, dst) in ((XA, TA, dst_a), (XB, TB, dst_b)):
+                xin = pair(x + 2 * col)
+                acc = pair(t + 2 * row)
+                if col == 0:
+                    out.append("v_mul_f64 %s, s[%d:%d], %s" % (acc, s, s + 1, xin))
+                elif col < 3:
+                    out.append("v_fma_f64 %s, s[%d:%d], %s, %s" % (acc, s, s + 1, xin, acc))
+                else:
+                    d = pair((dst[row]) if dst else x + 2 * row)
+                    out.append("v_fma_f64 %s, s[%d:%d], %s, %s" % (d, s, s + 1, xin, acc))
+    out += ["s_add_u32 s86, s86, 0x80", "s_addc_u32 s87, s87, 0",
+            "s_load_dwordx16 s[36:51], s[86:87], 0x0", "s_load_dwordx16 s[52:67], s[86:87], 0x40"]
+    return out
+
+
+def tipmul():
+    out = []
+    for i in range(4):
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XA + 2 * i), pair(XA + 2 * i), pair(PA + 2 * i)))
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XB + 2 * i), pair(XB + 2 * i), pair(PB + 2 * i)))
+    return out
+
+
+def tipset():
+    out = []
+    for i in range(4):
+        out.append("v_mov_b64 %s, %s" % (pair(XA + 2 * i), pair(PA + 2 * i)))
+        out.append("v_mov_b64 %s, %s" % (pair(XB + 2 * i), pair(PB + 2 * i)))
+    return out
+
+
+def tipnext():
+    return ["s_lshr_b32 s97, s96, 16", "s_and_b32 s98, s96, 0xffff",
+            "v_add_lshl_u32 v72, v74, s97, 5", "v_add_lshl_u32 v73, v75, s97, 5",
+            "ds_read_b128 v[56:59], v72", "ds_read_b128 v[60:63], v72 offset:16",
+            "ds_read_b128 v[64:67], v73", "ds_read_b128 v[68:71], v73 offset:16",
+            "v_lshl_add_u32 v76, s98, 6, v77",
+            "ds_read_u8 v74, v76", "@HALF ds_read_u8 v75, v76"]
+
+
+def push(d):
+    out = []
+    for i in range(4):
+        out.append("v_mov_b64 %s, %s" % (pair(slot_regs(d, 0)[i]), pair(XA + 2 * i)))
+        out.append("v_mov_b64 %s, %s" % (pair(slot_regs(d, 1)[i]), pair(XB + 2 * i)))
+    return out
+
+
+def popmul(d):
+    out = []
+    for i in range(4):
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XA + 2 * i), pair(XA + 2 * i), pair(slot_regs(d, 0)[i])))
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XB + 2 * i), pair(XB + 2 * i), pair(slot_regs(d, 1)[i])))
+    return out
+
+
+def scale():
+    out = []
+    for (x, tmp, esc) in ((XA, 80, 78), (XB, 81, 79)):
+        out += ["v_max_u32 v%d, v%d, v%d" % (tmp, x + 1, x + 3), "v_max3_u32 v%d, v%d, v%d, v%d" % (tmp, x + 5, x + 7, tmp),
+                "v_lshrrev_b32 v%d, 20, v%d" % (tmp, tmp), "v_sub_u32 v72, 0x3fe, v%d" % tmp]
+        out += ["v_ldexp_f64 %s, %s, v72" % (pair(x + 2 * i), pair(x + 2 * i)) for i in range(4)]
+        out.append("v_add3_u32 v%d, v%d, v%d, s95" % (esc, esc, tmp))
+    return out
+
+
+RET = ["s_setpc_b64 s[88:89]"]
+
+
+def handlers():
+    h = {}
+    h[0] = ["s_waitcnt lgkmcnt(0)"] + tipset() + tipnext() + RET
+    h[1] = ["s_waitcnt lgkmcnt(0)"] + tipmul() + tipnext() + RET
+    h[2] = matvec() + RET
+    h[3] = tipmul() + tipnext() + RET
+    h[4] = matvec() + tipmul() + tipnext() + RET
+    h[6] = scale() + RET
+    h[7] = ["s_branch .Ldone_%="]
+    for d in range(4):
+        h[8 + d] = push(d) + RET
+        h[16 + d] = popmul(d) + RET
+        h[24 + d] = matvec(slot_regs(d, 0), slot_regs(d, 1)) + RET
+        h[28 + d] = matvec() + popmul(d) + RET
+    return h
+
+
+def call(lo, hi):
+    return ["s_or_b32 s98, s90, s%d" % lo, "s_mov_b32 s96, s%d" % hi, "s_swappc_b64 s[88:89], s[98:99]"]
+
+
+def emit():
+    L = []           # (text, is_label)
+
+    def ins(lines):
+        for t in lines:
+            L.append(t)
+
+    # ---- prologue ----
+    pro = []
+    for i in range(4):
+        pro += ["v_mov_b32 v%d, 0" % (XA + 2 * i), "v_mov_b32 v%d, 0x3ff00000" % (XA + 2 * i + 1),
+                "v_mov_b32 v%d, 0" % (XB + 2 * i), "v_mov_b32 v%d, 0x3ff00000" % (XB + 2 * i + 1)]
+    pro += ["v_mov_b32 v78, 0", "v_mov_b32 v79, 0", "v_mov_b32 v77, %[clane]",
+            "s_mov_b64 s[84:85], %[ops]", "s_mov_b64 s[86:87], %[mstream]", "s_movk_i32 s95, 0xfc02",
+            "s_load_dwordx16 s[68:83], s[84:85], 0x0",
+            "s_load_dwordx16 s[36:51], s[86:87], 0x0", "s_load_dwordx16 s[52:67], s[86:87], 0x40",
+            # prefetch chain start: codes of the first observation, its values, codes of the second
+            "v_lshl_add_u32 v76, %[z0], 6, v77", "ds_read_u8 v74, v76", "@HALF ds_read_u8 v75, v76",
+            "s_getpc_b64 s[90:91]", ".Lpcref_%=:", "s_add_u32 s90, s90, .Lh0_%=-.Lpcref_%=", "s_addc_u32 s91, s91, 0",
+            "s_mov_b32 s99, s91", "s_waitcnt lgkmcnt(0)",
+            "v_add_lshl_u32 v72, v74, %[y0], 5", "v_add_lshl_u32 v73, v75, %[y0], 5",
+            "ds_read_b128 v[56:59], v72", "ds_read_b128 v[60:63], v72 offset:16",
+            "ds_read_b128 v[64:67], v73", "ds_read_b128 v[68:71], v73 offset:16",
+            "v_lshl_add_u32 v76, %[z1], 6, v77", "ds_read_u8 v74, v76", "@HALF ds_read_u8 v75, v76",
+            "s_waitcnt lgkmcnt(0)"]
+    ins(pro)
+    # ---- block loop, unrolled twice: no copies between the two op-block register sets ----
+    ins([".Lblock_%=:", "s_load_dwordx16 s[20:35], s[84:85], 0x40"])
+    for i in range(8):
+        ins(call(68 + 2 * i, 69 + 2 * i))
+    ins(["s_waitcnt lgkmcnt(0)", "s_load_dwordx16 s[68:83], s[84:85], 0x80", "s_add_u32 s84, s84, 0x80", "s_addc_u32 s85, s85, 0"])
+    for i in range(8):
+        ins(call(20 + 2 * i, 21 + 2 * i))
+    ins(["s_waitcnt lgkmcnt(0)", "s_branch .Lblock_%="])
+    # ---- handlers ----
+    h = handlers()
+    ins([".p2align 14", ".Lh0_%=:"])
+    for idx in range(32):
+        if idx:
+            ins([".p2align 9"])
+        ins(h.get(idx, RET))
+    ins([".p2align 9", ".Ldone_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
+    for i in range(4):
+        ins(["v_mov_b32 %%[a%dl], v%d" % (i, XA + 2 * i), "v_mov_b32 %%[a%dh], v%d" % (i, XA + 2 * i + 1),
+             "v_mov_b32 %%[b%dl], v%d" % (i, XB + 2 * i), "v_mov_b32 %%[b%dh], v%d" % (i, XB + 2 * i + 1)])
+    ins(["v_mov_b32 %[ea], v78", "v_mov_b32 %[eb], v79", "s_nop 1"])
+    return L
+
+
+def c_string(lines):
+    out = []
+    for t in lines:
+        if t.startswith("@HALF "):
+            body = t[6:]
+            out.append('        "%s offset:" #HALF "\\n\\t" \\' % body)
+        elif t.endswith(":") or t.startswith(".p2align"):
+            out.append('        "%s\\n" \\' % t)
+        else:
+            out.append('        "%s\\n\\t" \\' % t)
+    return "\n".join(out)
+
+
+def main():
+    lines = emit()
+    # size check: every handler must fit its slot (also checked on the object by tools/asm_layout_check.py)
+    sizes = {"v_mul_f64": 8, "v_fma_f64": 8, "v_mov_b64": 4, "v_mov_b32": 4, "v_max_u32": 4, "v_max3_u32": 8, "v_lshrrev_b32": 4,
+             "v_sub_u32": 8, "v_ldexp_f64": 8, "v_add3_u32": 8, "v_add_lshl_u32": 8, "v_lshl_add_u32": 8, "ds_read_b128": 8,
+             "ds_read_u8": 8, "s_waitcnt": 4, "s_add_u32": 8, "s_addc_u32": 4, "s_load_dwordx16": 8, "s_setpc_b64": 4,
+             "s_lshr_b32": 4, "s_and_b32": 8, "s_branch": 4}
+    for idx, body in handlers().items():
+        n = sum(sizes[b.replace("@HALF ", "").split()[0]] for b in body)
+        assert n <= HS, (idx, n)
+    vregs = ["v%d" % r for r in range(24, STACK0 + 64)]
+    sregs = ["s%d" % r for r in range(20, 100)]
+    hdr = '''/* GENERATED by tools/gen_fused4_v4.py -- do not edit; change the generator and run it again.
+ *
+ * Assembly text of k_ll_fused4_v4 (plk_fused4_v4.h): the k = 4 pair-table interpreter with two sites per lane.  Op
+ * format, handler numbering and the register map are documented in the generator. */
+#ifndef PLK_FUSED4_V4_ASM_H
+#define PLK_FUSED4_V4_ASM_H
+
+#define PLK_V4_HANDLER_BYTES %d
+
+/* HALF: sites between a lane's two sites = workgroup size (an integer literal: it is pasted into ds_read offsets) */
+#define PLK_V4_PROGRAM(HALF) \\
+%s
+        ""
+
+#define PLK_V4_CLOBBERS "memory", "scc", "vcc", \\
+        %s, \\
+        %s
+
+#endif
+''' % (HS, c_string(lines), ", ".join('"%s"' % v for v in vregs), ", ".join('"%s"' % s for s in sregs))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phyly_amd", "csrc", "plk_fused4_v4_asm.h")
+    with open(path, "w") as f:
+        f.write(hdr)
+    print("wrote", path, "(%d asm lines)" % len(lines))
+
+
+if __name__ == "__main__":
+    main()
