@@ -46,7 +46,7 @@ FP64_PEAK = 78.6e12        # flop/s, fp64 vector = fp64 matrix dense peak (SURVE
 
 # sources a kernel's measured HBM traffic depends on (profiles/traffic_*.json record their git blob hashes)
 KERNEL_SOURCES = {
-    "k_ll_fused4": ["plk_fused4_asm.h", "plk_fused4.h", "plk_program.h"],
+    "k_ll_fused4": ["plk_fused4_asm.h", "plk_fused4_v4.h", "plk_fused4_v4_asm.h", "plk_fused4.h", "plk_program.h"],
     "k_ll_vec": ["plk_vec.h", "plk_vec_matvec_asm.h"],
     "k_ll_mfma": ["plk_mfma.h"],
     "k_ll_generic": ["plk_engine.hip"],
@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--categories", type=int, default=0, help="override the number of Gamma categories (experiments; not the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
+    ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: block the compute stream on every all-reduce (no overlap with the next step)")
     ap.add_argument("--deriv-steps", type=int, default=3, help="steps of the edge-gradient leg (0 = skip)")
     ap.add_argument("--deriv-sites", type=int, default=0, help="sites per GPU of the edge-gradient leg (default: min(block, 2M))")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -238,15 +239,32 @@ def main():
 
     # the engine issues its kernels on torch's current stream: the all-reduce and the fences below are ordered with them
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    red = torch.zeros(2, dtype=torch.float64, device=dev)
+    # One {hi, lo} result per step in a small ring.  With N > 1 the all-reduce of step i is issued asynchronously
+    # (RCCL's own stream, ordered after the step's kernels by c10d) so that it overlaps the kernels of step i + 1: the
+    # evaluations are independent, nothing in step i + 1 reads the reduced sum of step i.  Every step still does its
+    # one all-reduce; all of them are waited for before the clock stops.  --sync-allreduce blocks the compute stream on
+    # each reduction instead (the latency-exposed figure; DESIGN.md section 5 quotes both).
+    RING = 4
+    red = torch.zeros((RING, 2), dtype=torch.float64, device=dev)
+    pending = []
+    state = {"i": 0}
 
     def step():
-        eng.update_edge_rates(wl.edge_rates_csr)       # new rates: K1 (+ stream + tip tables) runs again
-        eng.ll_async(sum_device_ptr=red.data_ptr())    # {hi, lo} of this rank's block, left on the device
+        i = state["i"] % RING
+        state["i"] += 1
+        if len(pending) >= RING - 1:
+            pending.pop(0).wait()                      # the slot about to be rewritten has been reduced
+        eng.update_edge_rates(wl.edge_rates_csr)       # new rates: K1 (+ stream + tables) runs again
+        eng.ll_async(sum_device_ptr=red[i].data_ptr()) # {hi, lo} of this rank's block, left on the device
         if use_dist:
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            if args.sync_allreduce:
+                dist.all_reduce(red[i], op=dist.ReduceOp.SUM)
+            else:
+                pending.append(dist.all_reduce(red[i], op=dist.ReduceOp.SUM, async_op=True))
 
     def fence():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -264,7 +282,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ns_sum, kern_count = eng.info(E.INFO_LL_KERNEL_NS_SUM), eng.info(E.INFO_LL_KERNEL_COUNT)
     assert kern_count == args.steps, (kern_count, args.steps)
-    total = float(red.sum().item())
+    total = float(red[(state["i"] - 1) % RING].sum().item())
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -334,7 +352,7 @@ def main():
         flops = alg["W_ll"] * S / kern_s
         kname = {1: "k_ll_fused4_asm", 2: "k_ll_generic", 3: "k_ll_mfma", 4: "k_ll_vec"}.get(kernel_kind, "?")
         if kernel_kind == 1:
-            kname = {1: "k_ll_fused4_asm", 3: "k_ll_fused4"}.get(eng.info(E.INFO_LL_VARIANT), kname)
+            kname = {1: "k_ll_fused4_asm", 3: "k_ll_fused4", 5: "k_ll_fused4_asm_pt", 6: "k_ll_fused4_v4"}.get(eng.info(E.INFO_LL_VARIANT), kname)
         # HBM bytes per launch from the PMC passes of the guide's recipe (profiles/traffic_cfgN.json, written by
         # tools/pmc_traffic.py from rocprofv3 --pmc runs of this kernel).  Only used when the file was measured at this
         # site count on the kernel sources of this very tree (git blob hashes); anything else is null, not a stale number.
@@ -349,20 +367,28 @@ def main():
         # the generic vector kernel streams its stack slots through HBM.
         fp64_bound = kernel_kind in (1, 3, 4) or alg["W_ll"] / FP64_PEAK > alg["A_ll"] / HBM_PEAK
         if fp64_bound:
-            # executed work: internal edges are full products (k^2 multiplies + k(k-1) fused multiply-adds), a leaf costs
-            # one k-wide multiply by its table row; what the fp64 pipe really issues, against the fp64 peak
-            k_, T_, C_ = wl.k, wl.T, wl.prepare()["C"]
-            kpad = k_ if kernel_kind != 3 else ((k_ + 15) // 16) * 16
-            exec_flops = C_ * ((wl.E - T_) * (2 * kpad * kpad - kpad) + T_ * k_)
+            # executed work, counted by the engine from the program the kernel ran (PLK_INFO_LL_EXEC_FLOPS): 2k^2 - k per
+            # matrix-vector product (k padded to 16 rows on the matrix cores), k per elementwise multiply; table look-ups
+            # (leaf rows, two-leaf subtrees), moves and rescaling count nothing
+            exec_flops = eng.info(E.INFO_LL_EXEC_FLOPS)
+            npairs = eng.info(E.INFO_PAIR_TABLES)
+            r02_flops = wl.prepare()["C"] * ((wl.E - wl.T) * (2 * wl.k * wl.k - wl.k) + wl.T * wl.k)
             roofline = dict(bound="fp64", achieved=exec_flops * S / kern_s / 1e12, peak=FP64_PEAK / 1e12, unit="TFLOP/s",
                             frac=exec_flops * S / kern_s / FP64_PEAK, traffic=traffic, kernel=kname, kernel_ms=kern_s * 1e3,
                             flops_per_site=exec_flops,
-                            note="EXECUTED fp64 work / kernel time / fp64 peak.  Executed flops per site = C x ((E - T) internal-edge "
-                                 "products of 2k^2 - k flops (k padded to 16 rows on the matrix cores) + T leaf multiplies of k flops); "
-                                 "leaf-edge products are table rows and are not counted, nor are stack and rescaling moves.  Peak 78.6 "
+                            pair_tables=npairs,
+                            note="EXECUTED fp64 work / kernel time / fp64 peak.  Executed flops per site are counted by the engine from "
+                                 "the traversal program that ran: 2k^2 - k per matrix-vector product (k padded to 16 rows on the matrix "
+                                 "cores) + k per elementwise multiply; leaf-edge products are table rows and, in the k = 4 pair-table "
+                                 "kernels, every two-leaf subtree with the edge above it is one table row: those products are not "
+                                 "executed and not counted, nor are stack and rescaling moves.  Peak 78.6 "
                                  "TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz, AMD's public MI355X figure for fp64 "
                                  "vector and matrix alike (MI355X_MICROARCH.md lists no fp64 peak).  Kernel time from HIP events "
                                  "over the %d timed launches on the kernel's stream" % kern_count,
+                            round2_work=dict(flops_per_site=r02_flops, ratio=r02_flops * S / kern_s / FP64_PEAK,
+                                             note="the work the round-2 kernels executed for this workload (every internal edge a "
+                                                  "product, every leaf a multiply) priced at this kernel's time: like-for-like speed "
+                                                  "against round 2's executed fraction, not a utilisation of this kernel"),
                             algorithmic=dict(flops_per_site=alg["W_ll"], achieved=flops / 1e12, ratio=flops / FP64_PEAK,
                                              note="SURVEY.md 8d's W_ll (a full product on every edge, leaf edges included) priced at "
                                                   "the kernel time: an equivalent rate, may exceed the peak, not a utilisation"),

@@ -207,7 +207,10 @@ enum {
     PLK_INFO_LL_KERNEL_COUNT = 6,   /* last read, and their number (reading waits for queued evaluations, then resets) */
     PLK_INFO_LL_VARIANT = 7,        /* k = 4 tile kernel of the last evaluation: 1 assembly interpreter, 3 C++ interpreter,
                                        5 assembly interpreter with pair tables, 6 the same with two sites per lane, 0 another kernel */
-    PLK_INFO_PAIR_TABLES = 8        /* two-leaf subtrees the last k = 4 evaluation read from tables */
+    PLK_INFO_PAIR_TABLES = 8,       /* two-leaf subtrees the last k = 4 evaluation read from tables */
+    PLK_INFO_LL_EXEC_FLOPS = 9      /* fp64 flops per site the last ll traversal kernel executed (all categories): 2k^2 - k per
+                                       matrix-vector product it ran (k padded to 16 rows on the matrix cores), k per elementwise
+                                       multiply (leaf rows, stack pops); table look-ups, moves and rescaling count nothing */
 };
 
 /* force the generic (HBM-resident partials) traversal even where the fused

@@ -136,7 +136,7 @@ struct plk_engine {
 
     /* options / info */
     long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1;
-    long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0;
+    long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0, info_ll_exec_flops = 0;
 };
 
 static std::string g_create_error;
@@ -580,6 +580,34 @@ __global__ void k_wsum_rows(long S, long row_stride, const double *__restrict__ 
     }
     dd r = dd_block_sum(acc);
     if (threadIdx.x == 0) partial[(size_t)row * nblocks + blockIdx.x] = r;
+}
+
+/* ---- site sums taken where the values are produced (site-aggregated marginals; src/arbplfmarginal.c:237-256) ----
+ * Cross-lane sums by data-parallel-primitive moves: every lane of a row of 16 ends with the row's sum (quad swaps,
+ * half-row mirror, row mirror), then row 3 collects the four rows (row broadcasts): lane 63 holds the sum of the 64
+ * lanes.  All lanes must be active; lanes without a site contribute 0.  Plain fp64 within the wave (a pairwise tree of
+ * 64 terms), double-double across waves afterwards (k_wsum_rows / k_dd_final). */
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += dpp_fetch<0xB1, 0xf>(x);      /* quad_perm [1,0,3,2] */
+    x += dpp_fetch<0x4E, 0xf>(x);      /* quad_perm [2,3,0,1] */
+    x += dpp_fetch<0x141, 0xf>(x);     /* row_half_mirror */
+    x += dpp_fetch<0x140, 0xf>(x);     /* row_mirror */
+    return x;
+}
+__device__ __forceinline__ double wave64_sum_lane63(double x)
+{
+    x = row16_sum(x);
+    x += dpp_fetch<0x142, 0xa>(x);     /* row_bcast15 into rows 1 and 3 */
+    x += dpp_fetch<0x143, 0xc>(x);     /* row_bcast31 into rows 2 and 3 */
+    return x;
 }
 
 #include "plk_fused4.h"
@@ -1215,6 +1243,7 @@ extern "C" int plk_get_info(plk_engine *h, int what, long *out)
     case PLK_INFO_LL_KERNEL_COUNT: *out = h->evk_count; h->evk_count = 0; return PLK_OK;
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
     case PLK_INFO_LL_VARIANT: *out = h->info_ll_variant; return PLK_OK;
+    case PLK_INFO_LL_EXEC_FLOPS: *out = h->info_ll_exec_flops; return PLK_OK;
     case PLK_INFO_PAIR_TABLES: *out = h->fmt_pt && h->fmt_kind == 1 && !h->fmt_dirty ? h->fpt.npairs : 0; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
     case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
@@ -1513,7 +1542,7 @@ static bool build_fused_pt(plk_engine *h)
     if (h->obs_nodes.empty()) return false;
     struct Cand { int kind, tile; };
     std::vector<Cand> cands;
-    switch (h->opt_pair_tables) {
+    switch (h->opt_pair_tables & 7) {
     case 2: cands = {{1, 1024}}; break;
     case 3: cands = {{1, 512}}; break;
     case 5: cands = {{2, 1024}}; break;
@@ -1524,7 +1553,7 @@ static bool build_fused_pt(plk_engine *h)
         const long limit = (long)plk_pt_lds_limit(cd.tile);
         int max_pairs = INT_MAX;
         for (int attempt = 0; attempt < 3; attempt++) {
-            plk_fused_pt_build(h->N, h->indptr.data(), h->indices.data(), h->pg, h->nchar, max_pairs, h->fpt);
+            plk_fused_pt_build(h->N, h->indptr.data(), h->indices.data(), h->pg, h->nchar, max_pairs, h->fpt, cd.kind == 2);
             const long bytes = (long)plk_fused_pt_lds_bytes(h->fpt, h->nchar, cd.tile);
             if (bytes <= limit && h->fpt.units < 2048 && h->fpt.row_node.size() < 65536) { h->pt_kind = cd.kind; h->pt_tile_sites = cd.tile; return true; }
             if (h->fpt.npairs == 0) break;
@@ -1748,7 +1777,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
             const int ntiles = (int)((S + tile - 1) / tile);
             if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)ntiles + PLK_PARTIAL_OFF))) return rc; }
             const size_t lds_pt = plk_fused_pt_lds_bytes(f, h->nchar, tile);
-            std::string bad = plk_fused_check_pt(h->N, h->indptr.data(), h->indices.data(), h->pg, f, h->nchar, tile, lds_pt);
+            std::string bad = plk_fused_check_pt(h->N, h->indptr.data(), h->indices.data(), h->pg, f, h->nchar, tile, lds_pt, h->pt_kind == 2);
             if (bad.empty() && h->pt_kind == 2) bad = plk_fused_check_v4(f, h->fv4, h->nchar, tile, h->v4_tip_base, lds_pt);
             if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
             FusedPTArgs pa;
@@ -1757,7 +1786,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
             pa.f.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
             pa.words = h->d_words_pt; pa.row_nodes = h->d_row_nodes; pa.nwords = (int)(h->pt_kind == 2 ? h->fv4.words.size() : f.words.size());
             pa.first_unit = f.first_unit; pa.first_row = f.first_row; pa.second_row = f.second_row; pa.ntiles = ntiles;
-            pa.warm = 1;
+            pa.warm = (h->opt_pair_tables & 8) ? 0 : 1;      /* + 8: without the scalar-cache warm-up (measurements) */
             h->info_ll_variant = 5;
             if (h->pt_kind == 2) {
                 /* two sites per lane: one workgroup of tile / 2 lanes per CU */
@@ -1863,6 +1892,28 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         default: launch_generic<64>(h, a, grid); break;
         }
         h->info_ll_kernel = 2;
+    }
+    {
+        /* executed fp64 work per site (PLK_INFO_LL_EXEC_FLOPS): products and elementwise multiplies of the program that ran */
+        long nprod = 0, nmul = 0;
+        if (fused && h->fmt_pt) {
+            nprod = (long)h->fpt.mat_edge.size();
+            for (unsigned w : h->fpt.words) {
+                const unsigned hx = w & 31;
+                if (hx == OP_TIP_MUL || hx == PLK_WORD_TIPMUL_NOWAIT || hx == PLK_WORD_MATVEC_TIPMUL) nmul++;
+                if ((hx >= 16 && hx < 20) || hx >= 28 || (hx >= PLK_WORD_SET_POPMUL && hx < PLK_WORD_SET_POPMUL + 4)) nmul++;
+            }
+        } else {
+            for (const plk_op2 &o : h->ops) {
+                const int code = o.x & 0xff;
+                if (code == OP_MATVEC) nprod++;
+                /* leaf edges: a table row multiplied in (fused, vector and matrix-core kernels) or a full product (generic) */
+                if (code == OP_TIP_MUL || code == OP_NODE_MUL || code == OP_POPMUL) nmul++;
+                if ((code == OP_TIP_SET || code == OP_TIP_MUL) && !fused && !vec && !mfma) { nprod++; if (code == OP_TIP_MUL) nmul++; }
+            }
+        }
+        const long kp = mfma ? (h->k + 15) / 16 * 16 : h->k;
+        h->info_ll_exec_flops = (long)h->C * (nprod * (2 * kp * kp - kp) + nmul * h->k);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->evk[evi][1], h->stream));
@@ -2077,7 +2128,9 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
                        k, R, E, ntips, h->nchar, d_te, d_M, h->d_defs, h->K, d_dtip, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)nslots_m * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    /* site-summed marginals without per-site output: the up pass leaves per-wave sums (MVS) instead of the N k planes */
+    const bool msum_only = marg && !site_out && sums_out && !deriv;
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)nslots_m * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (msum_only ? ((size_t)N * k + 15) / 16 : (size_t)N * k) : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -2114,9 +2167,12 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
-        a.MV = p; if (marg) p += (size_t)N * k * n;
+        const size_t nwv = (size_t)grid * (MF_BLOCK / 64);
+        a.MV = p; a.MVS = nullptr; a.wsite = nullptr;
+        if (marg && msum_only) { a.MVS = p; a.wsite = h->d_w ? h->d_w + s0 : nullptr; p += (size_t)N * k * nwv; }
+        else if (marg) p += (size_t)N * k * n;
         if (deriv && edge_mask) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));   /* without a mask every edge's row is written by the up pass */
-        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * k * nwv : (size_t)N * k * n) * sizeof(double), h->stream));
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
         a.visits = nodes ? pk + o_vis : nullptr; a.nvisits = un.nvisits;
         const bool nv = nodes && (s0 % MF_SITES) == 0;       /* chunks start at multiples of the site tile */
@@ -2128,7 +2184,8 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;
             if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
-            if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
+            if (marg && msum_only) { if ((rc = wsum_rows(h, N * k, (long)nwv, a.MVS, nullptr, msum.data()))) { cleanup(); return rc; } }
+            else if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
         if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)E : (size_t)N * k, n, s0, deriv ? a.DV : a.MV, site_out))) { cleanup(); return rc; }
     }
@@ -2246,7 +2303,8 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
                            E, ntips, h->nchar, d_te, d_M + (size_t)m * C * E * 16, h->d_defs, d_dtip4 + (size_t)m * ntab, dzero);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? ER : 0) + (marg ? (size_t)N * 4 : 0)) * sizeof(double);
+    const bool msum_only = marg && !site_out && sums_out && !deriv;      /* per-wave sums instead of the N x 4 planes */
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? ER : 0) + (marg ? (msum_only ? ((size_t)N * 4 + 63) / 64 : (size_t)N * 4) : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -2276,12 +2334,15 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)ER * n;
-        a.MV = p; if (marg) p += (size_t)N * 4 * n;
+        const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
+        const size_t nwv = (size_t)grid * (UD4_BLOCK / 64);
+        a.MV = p; a.MVS = nullptr; a.wsite = nullptr;
+        if (marg && msum_only) { a.MVS = p; a.wsite = h->d_w ? h->d_w + s0 : nullptr; p += (size_t)N * 4 * nwv; }
+        else if (marg) p += (size_t)N * 4 * n;
         a.visits = d_vis4; a.nvisits = un4.nvisits;
         /* (the node-visit pass writes the row of every wanted edge: rows need clearing only under a mask) */
         if (deriv && E > 0 && !(nodes4 && !edge_mask)) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
-        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * 4 * n * sizeof(double), h->stream));
-        const unsigned grid = (unsigned)((n + UD4_BLOCK - 1) / UD4_BLOCK);
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * 4 * nwv : (size_t)N * 4 * n) * sizeof(double), h->stream));
         const size_t lds_codes = (size_t)nobs2 * UD4_BLOCK;
         const bool fused_ok = d_ops2 && lds_codes <= 60 * 1024 && (s0 % UD4_BLOCK) == 0;
         if (fused_ok && h->slots_needed <= 4) hipLaunchKernelGGL(k_down_fused4<4>, dim3(grid), dim3(UD4_BLOCK), lds_codes, h->stream, a, d_ops2, d_oe2, (int)h->ops.size(), d_obs2, nobs2, first_slot2, first_row2);
@@ -2300,7 +2361,8 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;
             if (deriv && E > 0 && (rc = wsum_rows(h, ER, n, a.DV, w, dsum.data()))) { cleanup(); return rc; }
-            if (marg && (rc = wsum_rows(h, N * 4, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
+            if (marg && msum_only) { if ((rc = wsum_rows(h, N * 4, (long)nwv, a.MVS, nullptr, msum.data()))) { cleanup(); return rc; } }
+            else if (marg && (rc = wsum_rows(h, N * 4, n, a.MV, w, msum.data()))) { cleanup(); return rc; }
         }
         if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)ER : (size_t)N * 4, n, s0, deriv ? a.DV : a.MV, site_out))) { cleanup(); return rc; }
     }
@@ -2395,7 +2457,8 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
                        k, K, E, ntips, h->nchar, b + o_te, d_M, h->d_defs, K, d_dtipv, dzero);
     if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
-    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * K + (size_t)nslots * K + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (size_t)N * k : 0)) * sizeof(double);
+    const bool msum_only = marg && !site_out && sums_out && !deriv;      /* per-wave sums instead of the N x k planes */
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * K + (size_t)nslots * K + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (msum_only ? ((size_t)N * k + 63) / 64 : (size_t)N * k) : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
@@ -2425,17 +2488,21 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         a.XC = p; p += (size_t)C * n;
         a.LH = p; p += n;
         a.DV = p; if (deriv) p += (size_t)E * n;
-        a.MV = p; if (marg) p += (size_t)N * k * n;
-        if (deriv && edge_mask) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));   /* without a mask every edge's row is written by the up pass */
-        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (size_t)N * k * n * sizeof(double), h->stream));
         const unsigned grid = (unsigned)((n + UDV_BLOCK - 1) / UDV_BLOCK);
+        const size_t nwv = (size_t)grid * (UDV_BLOCK / 64);
+        a.MV = p; a.MVS = nullptr; a.wsite = nullptr;
+        if (marg && msum_only) { a.MVS = p; a.wsite = h->d_w ? h->d_w + s0 : nullptr; p += (size_t)N * k * nwv; }
+        else if (marg) p += (size_t)N * k * n;
+        if (deriv && edge_mask) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)E * n * sizeof(double), h->stream));   /* without a mask every edge's row is written by the up pass */
+        if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * k * nwv : (size_t)N * k * n) * sizeof(double), h->stream));
         if (K == 16) launch_updown_vec<16>(h, a, b + o_obs, grid, deriv, marg);
         else launch_updown_vec<20>(h, a, b + o_obs, grid, deriv, marg);
         if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: kernel launch failed"; return PLK_E_DEVICE; }
         if (sums_out) {
             const double *w = h->d_w ? h->d_w + s0 : nullptr;
             if (deriv && (rc = wsum_rows(h, E, n, a.DV, w, dsum.data()))) return rc;
-            if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) return rc;
+            if (marg && msum_only) { if ((rc = wsum_rows(h, N * k, (long)nwv, a.MVS, nullptr, msum.data()))) return rc; }
+            else if (marg && (rc = wsum_rows(h, N * k, n, a.MV, w, msum.data()))) return rc;
         }
         if (site_out && (rc = copy_site_rows(h, deriv ? (size_t)E : (size_t)N * k, n, s0, deriv ? a.DV : a.MV, site_out))) return rc;
     }

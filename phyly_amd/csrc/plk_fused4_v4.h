@@ -27,35 +27,27 @@ struct FusedV4Args {
     unsigned first_y, first_z, second_z;     /* pre-scaled fields of the prefetch chain's start */
 };
 
-template <int THREADS>
-__device__ __forceinline__ void fused_run_program_v4(double (&xa)[4], double (&xb)[4], int &ea, int &eb, const void *ops,
-                                                      const void *mstream, unsigned clane, unsigned y0, unsigned z0, unsigned z1);
-
+/* runs the program of one category for the lane's two sites: root dot products lh (w . root vector) and scale exponents */
 #define PLK_V4_RUN(HALF)                                                                                             \
     asm volatile(PLK_V4_PROGRAM(HALF)                                                                                \
-                 : [a0l] "=v"(al[0]), [a0h] "=v"(ah[0]), [a1l] "=v"(al[1]), [a1h] "=v"(ah[1]),                       \
-                   [a2l] "=v"(al[2]), [a2h] "=v"(ah[2]), [a3l] "=v"(al[3]), [a3h] "=v"(ah[3]),                       \
-                   [b0l] "=v"(bl[0]), [b0h] "=v"(bh[0]), [b1l] "=v"(bl[1]), [b1h] "=v"(bh[1]),                       \
-                   [b2l] "=v"(bl[2]), [b2h] "=v"(bh[2]), [b3l] "=v"(bl[3]), [b3h] "=v"(bh[3]),                       \
-                   [ea] "=v"(ea), [eb] "=v"(eb)                                                                      \
-                 : [clane] "v"(clane), [ops] "s"(ops), [mstream] "s"(mstream), [y0] "s"(y0), [z0] "s"(z0), [z1] "s"(z1) \
+                 : [al] "=v"(al), [ah] "=v"(ah), [bl] "=v"(bl), [bh] "=v"(bh), [ea] "=v"(ea), [eb] "=v"(eb)          \
+                 : [clane] "v"(clane), [ops] "s"(ops), [mstream] "s"(mstream), [y0] "s"(y0), [z0] "s"(z0), [z1] "s"(z1), \
+                   [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3)                                            \
                  : PLK_V4_CLOBBERS)
 
-template <>
-__device__ __forceinline__ void fused_run_program_v4<512>(double (&xa)[4], double (&xb)[4], int &ea, int &eb, const void *ops,
-                                                           const void *mstream, unsigned clane, unsigned y0, unsigned z0, unsigned z1)
+template <int THREADS>
+__device__ __forceinline__ void fused_run_program_v4(double &lha, double &lhb, int &ea, int &eb, const void *ops, const void *mstream,
+                                                      unsigned clane, unsigned y0, unsigned z0, unsigned z1,
+                                                      double w0, double w1, double w2, double w3)
 {
-    int al[4], ah[4], bl[4], bh[4];
-    PLK_V4_RUN(512);
-    for (int i = 0; i < 4; i++) { xa[i] = __hiloint2double(ah[i], al[i]); xb[i] = __hiloint2double(bh[i], bl[i]); }
-}
-template <>
-__device__ __forceinline__ void fused_run_program_v4<768>(double (&xa)[4], double (&xb)[4], int &ea, int &eb, const void *ops,
-                                                           const void *mstream, unsigned clane, unsigned y0, unsigned z0, unsigned z1)
-{
-    int al[4], ah[4], bl[4], bh[4];
-    PLK_V4_RUN(768);
-    for (int i = 0; i < 4; i++) { xa[i] = __hiloint2double(ah[i], al[i]); xb[i] = __hiloint2double(bh[i], bl[i]); }
+    int al, ah, bl, bh;
+#ifdef PLK_EXP_EMPTY
+    al = bl = 0; ah = bh = 0x3ff00000; ea = eb = 0;
+#else
+    if constexpr (THREADS == 512) { PLK_V4_RUN(512); } else { static_assert(THREADS == 768, "tile"); PLK_V4_RUN(768); }
+#endif
+    lha = __hiloint2double(ah, al);
+    lhb = __hiloint2double(bh, bl);
 }
 
 template <int THREADS>
@@ -74,6 +66,10 @@ __global__ __launch_bounds__(THREADS) void k_ll_fused4_v4(FusedV4Args va)
     const PLK_AS4 double *prior = as_uniform(a.cat_prior);
     const PLK_AS4 double *rootw = as_uniform(a.root_w);
     const unsigned clane = (unsigned)(size_t)code_lds + (unsigned)tid;
+    /* root weights of the dot product at the end of the program: 1 (no prior), 1/4 (uniform) or the given distribution */
+    const bool plain = a.root_mode == PLK_ROOT_NONE || a.root_mode == PLK_ROOT_UNIFORM;
+    const double wu = a.root_mode == PLK_ROOT_NONE ? 1.0 : 0.25;
+    const double rw0 = plain ? wu : rootw[0], rw1 = plain ? wu : rootw[1], rw2 = plain ? wu : rootw[2], rw3 = plain ? wu : rootw[3];
 
     for (int tile = blockIdx.x; tile < aa.ntiles; tile += gridDim.x) {
         const long tile0 = (long)tile * TILE;
@@ -127,16 +123,13 @@ __global__ __launch_bounds__(THREADS) void k_ll_fused4_v4(FusedV4Args va)
                 }
             }
             __syncthreads();
-            double x[2][4];
+            double lhs[2];
             int esc[2];
-            fused_run_program_v4<THREADS>(x[0], x[1], esc[0], esc[1], aa.words, a.PS + (size_t)c * (a.nmat + 1) * 16, clane,
-                                          va.first_y, va.first_z, va.second_z);
+            fused_run_program_v4<THREADS>(lhs[0], lhs[1], esc[0], esc[1], aa.words, a.PS + (size_t)c * (a.nmat + 1) * 16, clane,
+                                          va.first_y, va.first_z, va.second_z, rw0, rw1, rw2, rw3);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                double lh;
-                if (a.root_mode == PLK_ROOT_NONE) lh = ((x[j][0] + x[j][1]) + x[j][2]) + x[j][3];
-                else if (a.root_mode == PLK_ROOT_UNIFORM) lh = (((x[j][0] + x[j][1]) + x[j][2]) + x[j][3]) * 0.25;
-                else lh = fma(rootw[3], x[j][3], fma(rootw[2], x[j][2], fma(rootw[1], x[j][1], rootw[0] * x[j][0])));
+                const double lh = lhs[j];
                 const double term = prior[c] * lh;
                 if (term != 0.0) {
                     if (!have[j]) { sum[j] = term; Eexp[j] = esc[j]; have[j] = true; }

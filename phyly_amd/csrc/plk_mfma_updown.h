@@ -39,6 +39,8 @@ struct MUpArgs {
     double *LH;                   /* [n], at the common exponent Xmax */
     double *DV;                   /* [E][n] */
     double *MV;                   /* [N][k][n] */
+    double *MVS;                  /* site-summed marginals only: [(node * k + state)][nwaves] weighted sums of a wave's 16 sites */
+    const double *wsite;          /* [n] site weights of the chunk or null */
     /* node-visit up pass (k_up_nodes_mfma): records of plk_up_nodes_build(), and fragD holds the fragments of M^T */
     const int *visits;
     int nvisits;
@@ -365,6 +367,20 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+/* marginal of NODE: states g, g + 4, ... of this lane's site (a site is spread over the four lanes {s, s + 16, s + 32,
+ * s + 48}).  Per-site planes, or -- site sums only -- the weighted sum over the 16 sites of the wave, taken within each
+ * row of 16 lanes; lane 15 of row g stores the states g + 4r.  All lanes take part. */
+#define MF_OUT_M(NODE, MACC)                                                                              \
+    do { if (a.MVS) {                                                                                      \
+             const double ws_ = valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv : 0.0;                        \
+             const size_t nwv_ = (size_t)gridDim.x * (MF_BLOCK / 64), wv_ = (size_t)blockIdx.x * (MF_BLOCK / 64) + wave; \
+             _Pragma("unroll") for (int r = 0; r < R; r++) {                                               \
+                 const double t_ = row16_sum(MACC[r] * ws_);                                               \
+                 if (g + 4 * r < a.k && (lane & 15) == 15) a.MVS[((size_t)(NODE) * a.k + g + 4 * r) * nwv_ + wv_] = t_; } \
+         } else {                                                                                          \
+             _Pragma("unroll") for (int r = 0; r < R; r++)                                                 \
+                 if (g + 4 * r < a.k && valid) a.MV[((size_t)(NODE) * a.k + g + 4 * r) * n + sl] = MACC[r] * inv; } } while (0)
+
 template <int T, bool DERIV, bool MARG>
 __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_up_mfma(MUpArgs a)
 {
@@ -400,11 +416,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                 for (int r = 0; r < R; r++) macc[r] = fma(as_uniform(a.cat_prior)[c] * a.CW[(size_t)c * n + slc] * f[r], l[r], macc[r]);
             }
         }
-        if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) {
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (g + 4 * r < a.k && valid) a.MV[((size_t)root * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
-        }
+        if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) MF_OUT_M(root, macc);
     }
 
     for (int u = 0; u < a.N; u++) {
@@ -490,11 +502,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                 }
             }
             if (want_d && valid && g == 0) a.DV[(size_t)idx * n + sl] = dsum * inv;
-            if (want_m) {
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    if (g + 4 * r < a.k && valid) a.MV[((size_t)b * a.k + g + 4 * r) * n + sl] = macc[r] * inv;
-            }
+            if (want_m) MF_OUT_M(b, macc);
         }
     }
 }

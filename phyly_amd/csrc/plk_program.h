@@ -32,6 +32,8 @@ enum {
 };
 /* handler 3 of the assembly interpreter's word format: TIP_MUL that may skip its wait (plk_fused4_asm.h) */
 #define PLK_WORD_TIPMUL_NOWAIT 3u
+#define PLK_WORD_SET_POPMUL 12u        /* + slot: TIP_SET and the POPMUL that follows it (two-sites-per-lane interpreter only) */
+#define PLK_WORD_SET_PUSH 20u          /* + slot: TIP_SET and the PUSH that follows it */
 #define PLK_WORD_MATVEC_TIPMUL 4u      /* assembly interpreter: MATVEC and the TIP_MUL that follows it, as one op word (handler slots 4 and 5) */
 
 struct plk_op2 { int x, y; };          /* layout of HIP's int2: x = opcode | tip_slot << 8, y = node / stack slot */
@@ -459,7 +461,8 @@ static inline bool plk_pair_at(int N, const int *ip, const int *ix, const PlkPro
 }
 
 /* max_pairs: how many cherries may become tables (LDS budget); nchar * nchar <= 256 is the caller's business */
-static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const PlkProgram &pg, int nchar, int max_pairs, PlkFusedPT &fu)
+static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const PlkProgram &pg, int nchar, int max_pairs, PlkFusedPT &fu,
+                                      bool fuse_set = false)
 {
     const int nops = (int)pg.ops.size();
     struct VOp { int code, unit, row, d; };
@@ -529,8 +532,15 @@ static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const
             }
         }
         if (code == OP_TIP_SET || code == OP_TIP_MUL) {
-            const unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
-                                                   : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
+            unsigned oc = code == OP_TIP_SET ? (unsigned)OP_TIP_SET
+                                             : (matvec_since_obs && oi > 0 ? PLK_WORD_TIPMUL_NOWAIT : (unsigned)OP_TIP_MUL);
+            const int nx = i + 1 < nv ? v[i + 1].code : OP_END;
+            if (fuse_set && code == OP_TIP_SET && (nx == OP_POPMUL || nx == OP_PUSH)) {
+                /* TIP_SET followed by POPMUL / PUSH (a look-up as the last or as an earlier internal child): one word, handlers
+                 * 12 + d / 20 + d of the two-sites-per-lane interpreter; the value goes straight into the product / the slot */
+                oc = (nx == OP_POPMUL ? PLK_WORD_SET_POPMUL : PLK_WORD_SET_PUSH) + (unsigned)v[i + 1].d;
+                i++;
+            }
             wv = oc | obs_fields();
             matvec_since_obs = false;
             oi++;
@@ -556,7 +566,7 @@ static inline size_t plk_fused_pt_lds_bytes(const PlkFusedPT &fu, int nchar, int
  * next leaf op -- or, for a pair table, stand for exactly TIP_SET(b), TIP_MUL(c), MATVEC(edge above) of one cherry.
  */
 static inline std::string plk_fused_check_pt(int N, const int *ip, const int *ix, const PlkProgram &pg, const PlkFusedPT &fu, int nchar,
-                                             int tile, size_t lds_bytes_launched)
+                                             int tile, size_t lds_bytes_launched, bool fused_set_words = false)
 {
     const int nops = (int)pg.ops.size(), nrows = (int)fu.row_node.size(), nmat = (int)fu.mat_edge.size(), ntab = (int)fu.tab_unit.size();
     if (nchar < 1 || nchar > 16) return "pt program: pair tables need nchar <= 16";
@@ -634,8 +644,22 @@ static inline std::string plk_fused_check_pt(int N, const int *ip, const int *ix
             const unsigned w = fu.words[wi];
             const unsigned hidx = w & 31, z = w >> 16;
             if (hidx == 5) return plk_fmt("pt program: word %ld jumps to an empty handler slot", (long)wi);
-            const unsigned y = hidx >= 24 ? (hidx & 3) : hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
+            const bool setstack = (hidx >= PLK_WORD_SET_POPMUL && hidx < PLK_WORD_SET_POPMUL + 4) || (hidx >= PLK_WORD_SET_PUSH && hidx < PLK_WORD_SET_PUSH + 4);
+            if (setstack && !fused_set_words) return plk_fmt("pt program: word %ld jumps to an empty handler slot", (long)wi);
+            const unsigned y = setstack ? (w >> 5) & 0x7ff : hidx >= 24 ? (hidx & 3) : hidx >= 8 ? (hidx & 7) : (w >> 5) & 0x7ff;
             std::string bad;
+            if (setstack) {
+                /* TIP_SET (single or pair look-up), then POPMUL / PUSH of slot hidx & 3 */
+                bad = observation(wi, y, z, true, false);
+                if (!bad.empty()) return bad;
+                const bool push = hidx >= PLK_WORD_SET_PUSH;
+                const unsigned d = hidx & 3;
+                if (code_at(pc) != (push ? OP_PUSH : OP_POPMUL) || (int)d != pg.ops[pc].y || (full[d] != 0) == push)
+                    return plk_fmt(push ? "pt program: bad SET + PUSH at word %ld" : "pt program: bad SET + POPMUL at word %ld", (long)wi);
+                full[d] = push;
+                pc++;
+                continue;
+            }
             if (hidx == OP_END) {
                 if ((int)pc != nops) return plk_fmt("pt program: END at word %ld after %ld of the program's ops", (long)wi, (long)pc);
                 if (mi != nmat) return "pt program: matrix stream not consumed";
@@ -673,7 +697,8 @@ struct PlkFusedV4 {
 
 static inline bool plk_word_is_obs(unsigned hidx)
 {
-    return hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT || hidx == PLK_WORD_MATVEC_TIPMUL;
+    return hidx == OP_TIP_SET || hidx == OP_TIP_MUL || hidx == PLK_WORD_TIPMUL_NOWAIT || hidx == PLK_WORD_MATVEC_TIPMUL ||
+           (hidx >= PLK_WORD_SET_POPMUL && hidx < PLK_WORD_SET_POPMUL + 4) || (hidx >= PLK_WORD_SET_PUSH && hidx < PLK_WORD_SET_PUSH + 4);
 }
 
 static inline void plk_fused_v4_words(const PlkFusedPT &fu, int nchar, int tile, unsigned tip_base, PlkFusedV4 &v4)

@@ -44,6 +44,10 @@ struct Up4Args {
     double *SC;                    /* [(slot*C + c)][n]: 2^-e applied to L_a at rescaled nodes */
     double *CW, *XC;               /* [C][n]: 2^(X_c - Xmax); scratch: X_c and category likelihood mantissas */
     double *LH, *DV, *MV;          /* [n] (at exponent Xmax), [E][n], [N][4][n] */
+    /* site-summed marginals (no per-site output asked for): MV is not written; every wave leaves the weighted sum of its
+     * 64 sites in MVS[(node * 4 + state) * nwaves + wave] (src/arbplfmarginal.c:237-256 accumulates as it goes, too) */
+    double *MVS;                   /* null: per-site planes in MV */
+    const double *wsite;           /* [n] site weights of the chunk or null */
     const int *visits;             /* k_up4_nodes: records of plk_up_nodes_build() (plk_program.h) */
     int nvisits;
 };
@@ -368,6 +372,26 @@ __device__ static inline void ud4_pre_step(const Up4Args &a, int c, const double
     }
 }
 
+
+/* marginal of one node at this lane's site: a plane entry per state, or -- site sums only -- the wave's weighted sum.
+ * Called by all lanes of the wave (uniform control flow); lanes without a site pass valid = false. */
+__device__ static inline void ud4_out_m(const Up4Args &a, size_t n, long sl, bool valid, int node, const v4 &m, double inv)
+{
+    if (a.MVS) {
+        const double ws = valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv : 0.0;
+        const double s0 = wave64_sum_lane63(m.a * ws), s1 = wave64_sum_lane63(m.b * ws);
+        const double s2 = wave64_sum_lane63(m.c * ws), s3 = wave64_sum_lane63(m.d * ws);
+        if ((threadIdx.x & 63) == 63) {
+            const size_t nw = (size_t)gridDim.x * (UD4_BLOCK / 64), wv = (size_t)blockIdx.x * (UD4_BLOCK / 64) + (threadIdx.x >> 6);
+            double *p = a.MVS + (size_t)node * 4 * nw + wv;
+            p[0] = s0; p[nw] = s1; p[2 * nw] = s2; p[3 * nw] = s3;
+        }
+    } else if (valid) {
+        double *mv = a.MV + (size_t)node * 4 * n + sl;
+        mv[0] = m.a * inv; mv[n] = m.b * inv; mv[2 * n] = m.c * inv; mv[3 * n] = m.d * inv;
+    }
+}
+
 template <int NM>
 __device__ static inline void ud4_pre_write(const Up4Args &a, size_t n, long sl, double inv, const Ud4Pre &q,
                                             const double (&pd0)[NM], const double (&pd1)[NM], const v4 &pm0, const v4 &pm1)
@@ -377,14 +401,7 @@ __device__ static inline void ud4_pre_write(const Up4Args &a, size_t n, long sl,
         if (q.wd0) a.DV[((size_t)m * a.E + q.idx0) * n + sl] = pd0[m] * inv;
         if (q.wd1) a.DV[((size_t)m * a.E + q.idx1) * n + sl] = pd1[m] * inv;
     }
-    if (q.wm0) {
-        double *mv = a.MV + (size_t)q.b0 * 4 * n + sl;
-        mv[0] = pm0.a * inv; mv[n] = pm0.b * inv; mv[2 * n] = pm0.c * inv; mv[3 * n] = pm0.d * inv;
-    }
-    if (q.wm1) {
-        double *mv = a.MV + (size_t)q.b1 * 4 * n + sl;
-        mv[0] = pm1.a * inv; mv[n] = pm1.b * inv; mv[2 * n] = pm1.c * inv; mv[3 * n] = pm1.d * inv;
-    }
+    (void)pm0; (void)pm1;          /* the marginals of the two leaves go through ud4_out_m (all lanes of the wave) */
 }
 
 template <bool DERIV, bool MARG, int NM = 1>
@@ -419,10 +436,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                 macc.c = fma(pc * w.c, l.c, macc.c); macc.d = fma(pc * w.d, l.d, macc.d);
             }
         }
-        if (MARG && valid && (!a.node_mask || as_uniform(a.node_mask)[root])) {
-            double *mv = a.MV + (size_t)root * 4 * n + sl;
-            mv[0] = macc.a * inv; mv[n] = macc.b * inv; mv[2 * n] = macc.c * inv; mv[3 * n] = macc.d * inv;
-        }
+        if (MARG && (!a.node_mask || as_uniform(a.node_mask)[root])) ud4_out_m(a, n, sl, valid, root, macc, inv);
     }
 
     for (int u = 0; u < a.N; u++) {
@@ -509,14 +523,14 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
                     if (c0.want_d) a.DV[((size_t)m * a.E + c0.idx) * n + sl] = d0[m] * inv;
                     if (c1.want_d) a.DV[((size_t)m * a.E + c1.idx) * n + sl] = d1[m] * inv;
                 }
-                if (c0.want_m) {
-                    double *mv = a.MV + (size_t)c0.b * 4 * n + sl;
-                    mv[0] = m0.a * inv; mv[n] = m0.b * inv; mv[2 * n] = m0.c * inv; mv[3 * n] = m0.d * inv;
-                }
-                if (c1.want_m) {
-                    double *mv = a.MV + (size_t)c1.b * 4 * n + sl;
-                    mv[0] = m1.a * inv; mv[n] = m1.b * inv; mv[2 * n] = m1.c * inv; mv[3 * n] = m1.d * inv;
-                }
+            }
+            if (MARG) {
+                if (in0 && q0.wm0) ud4_out_m(a, n, sl, valid, q0.b0, r00, inv);
+                if (in0 && q0.wm1) ud4_out_m(a, n, sl, valid, q0.b1, r01, inv);
+                if (in1 && q1.wm0) ud4_out_m(a, n, sl, valid, q1.b0, r10, inv);
+                if (in1 && q1.wm1) ud4_out_m(a, n, sl, valid, q1.b1, r11, inv);
+                if (c0.want_m) ud4_out_m(a, n, sl, valid, c0.b, m0, inv);
+                if (c1.want_m) ud4_out_m(a, n, sl, valid, c1.b, m1, inv);
             }
             continue;
         }
@@ -579,10 +593,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_up4(Up4Args a)
 #pragma unroll
                 for (int m = 0; m < NM; m++) a.DV[((size_t)m * a.E + idx) * n + sl] = dsum[m] * inv;
             }
-            if (ch.want_m && valid) {
-                double *mv = a.MV + (size_t)ch.b * 4 * n + sl;
-                mv[0] = macc.a * inv; mv[n] = macc.b * inv; mv[2 * n] = macc.c * inv; mv[3 * n] = macc.d * inv;
-            }
+            if (ch.want_m) ud4_out_m(a, n, sl, valid, ch.b, macc, inv);
         }
     }
 }

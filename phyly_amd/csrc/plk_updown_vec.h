@@ -52,6 +52,8 @@ struct UpVecArgs {
     double *slots;                 /* [slot][K][n] */
     double *SC, *CW, *XC;          /* as Up4Args */
     double *LH, *DV, *MV;          /* [n], [E][n], [N][k][n] */
+    double *MVS;                   /* site-summed marginals only: [(node * k + state)][nwaves] per-wave weighted sums, MV unused */
+    const double *wsite;           /* [n] site weights of the chunk or null */
 };
 
 /* child record of a visit: 4 ints */
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
     const double inv = 1.0 / a.LH[slc];
     constexpr int KK = K * K;
+    const size_t nwv = (size_t)gridDim.x * (UDV_BLOCK / 64), wv = (size_t)blockIdx.x * (UDV_BLOCK / 64) + (threadIdx.x >> 6);
 
     {   /* root: forward vector = root prior weights; its marginal */
         const int root = vis[0], root_int = vis[2];
@@ -247,10 +250,19 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 for (int i = 0; i < K; i++) macc[i] = fma(pc * f[i], l[i], macc[i]);
             }
         }
-        if (MARG && valid && vis[6]) {
+        if (MARG && vis[6]) {
+            if (a.MVS) {
+                const double ws = valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv : 0.0;
 #pragma unroll
-            for (int i = 0; i < K; i++)
-                if (i < a.k) a.MV[((size_t)root * a.k + i) * n + sl] = macc[i] * inv;
+                for (int i = 0; i < K; i++) {
+                    const double t_ = wave64_sum_lane63(macc[i] * ws);
+                    if (i < a.k && (threadIdx.x & 63) == 63) a.MVS[((size_t)root * a.k + i) * nwv + wv] = t_;
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int i = 0; i < K; i++)
+                    if (i < a.k) a.MV[((size_t)root * a.k + i) * n + sl] = macc[i] * inv;
+            }
         }
     }
 
@@ -288,7 +300,14 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
             do { if (valid) { double *dp_ = a.DV + (size_t)(EDGE) * n + sl;                               \
                  const double t_ = (VAL); *dp_ = (first_cat ? t_ : *dp_ + t_) * (last_cat ? inv : 1.0); } } while (0)
 #define UDV_OUT_M(NODE, FB, LB)                                                                           \
-            do { if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {                \
+            do { if (a.MVS) {      /* site sums only: the wave's weighted sum of this category's term, accumulated per wave */ \
+                     const double wi_ = valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv * pc : 0.0;          \
+                     _Pragma("unroll") for (int i = 0; i < K; i++) {                                      \
+                         const double t_ = wave64_sum_lane63(wi_ * FB[i] * LB[i]);                        \
+                         if (i < a.k && (threadIdx.x & 63) == 63) {                                       \
+                             double *mp_ = a.MVS + ((size_t)(NODE) * a.k + i) * nwv + wv;                 \
+                             *mp_ = first_cat ? t_ : *mp_ + t_; } }                                       \
+                 } else if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {         \
                  double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
                  const double t_ = pc * FB[i] * LB[i]; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
 

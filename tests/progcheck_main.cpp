@@ -190,6 +190,26 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
                 if (fp.tab_eb[q] >= 0) { seen[fp.tab_eb[q]]++; seen[fp.tab_ec[q]]++; }
             }
             for (int e = 0; e < E; e++) if (seen[e] != 1) return "pt: edge " + std::to_string(e) + " covered " + std::to_string(seen[e]) + " times";
+            {
+                /* the two-sites-per-lane interpreter's words: TIP_SET + POPMUL / PUSH fused, re-encoded as 64-bit ops */
+                PlkFusedPT fq;
+                plk_fused_pt_build(N, t.ip.data(), t.ix.data(), pg, nchar, budgets[bi], fq, true);
+                const int tile4 = (N + bi) % 2 ? 1024 : 1536;
+                const size_t lds4 = plk_fused_pt_lds_bytes(fq, nchar, tile4);
+                if (lds4 <= plk_pt_lds_limit(tile4) && fq.units < 2048) {
+                    bad = plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, fq, nchar, tile4, lds4, true);
+                    if (!bad.empty()) return "v4 words, budget " + std::to_string(bi) + ": " + bad;
+                    if (fq.words != fp.words && plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, fq, nchar, tile4, lds4, false).empty())
+                        return "negative control (v4): fused SET words accepted by the one-site interpreter's check";
+                    PlkFusedV4 v4;
+                    plk_fused_v4_words(fq, nchar, tile4, 256, v4);
+                    bad = plk_fused_check_v4(fq, v4, nchar, tile4, 256, lds4);
+                    if (!bad.empty()) return "v4 encoding: " + bad;
+                    PlkFusedV4 v5 = v4;
+                    v5.words[1] += 1u << 16;
+                    if (plk_fused_check_v4(fq, v5, nchar, tile4, 256, lds4).empty() && plk_word_is_obs(fq.words[0] & 31)) return "negative control (v4): shifted table offset accepted";
+                }
+            }
             if (bi != 0) continue;
             /* negative controls */
             if (plk_fused_check_pt(N, t.ip.data(), t.ix.data(), pg, fp, nchar, tile, lds - 1).empty()) return "negative control (pt): short LDS accepted";

@@ -86,6 +86,34 @@ def test_marginal_matches_oracle(eng, oracle, cfg, S):
     assert np.max(np.abs(tot - want.sum(axis=0))) <= 1e-12 * S
 
 
+@pytest.mark.parametrize("cfg,S", [(2, 1000), (3, 777), (4, 333), (5, 100), (5, 7)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_site_summed_marginal_is_reduced_where_it_is_produced(eng, cfg, S, masked):
+    """Site sums without per-site output (src/arbplfmarginal.c:237-256 accumulates as it goes): the up pass leaves per-wave
+    weighted sums, the N k planes are not written.  Same sums as the two-stage path (planes + k_wsum_rows, taken when
+    per-site values are asked for as well) to 1e-14 of the total site weight, with site weights, a node mask and a
+    ragged last wave."""
+    from phyly_amd import synth
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    codes = w.random_codes(S, seed=cfg) if cfg != 3 else w.simulate(S)
+    eng.set_patterns_codes(codes, w.defs)
+    wts = np.linspace(0.5, 1.5, S)
+    eng.set_site_weights(wts)
+    mask = None
+    if masked:
+        mask = (np.arange(w.N) % 3 != 1).astype(np.int32)
+    per_site, two_stage = eng.marginal(node_mask=mask)
+    _, fused = eng.marginal(node_mask=mask, per_site=False)
+    eng.set_site_weights(None)
+    a, b = two_stage[..., 0] + two_stage[..., 1], fused[..., 0] + fused[..., 1]
+    assert np.max(np.abs(a - b)) <= 1e-14 * wts.sum()
+    want = (per_site * wts[:, None, None]).sum(axis=0)
+    assert np.max(np.abs(b - want)) <= 1e-13 * wts.sum()
+    if masked:
+        assert np.all(b[mask == 0] == 0.0)
+
+
 def test_marginal_node_mask_dense(eng, oracle):
     """dense observations with data on internal nodes; only some nodes requested"""
     from phyly_amd import synth

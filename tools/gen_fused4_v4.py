@@ -13,7 +13,8 @@ Op format (built by plk_fused_v4_words in plk_program.h from the pair-table prog
   hi dword  observation ops: bits 31:16 = LDS offset / 32 of the table the NEXT observation op reads, bits 15:0 = LDS
             offset / 64 of the staged code row of the observation op AFTER the next (both relative to LDS address 0)
 Handler indices: 0 TIP_SET, 1 TIP_MUL, 2 MATVEC, 3 TIP_MUL without wait, 4 MATVEC + TIP_MUL, 6 SCALE, 7 END,
-8 + d PUSH slot d, 16 + d POPMUL slot d, 24 + d MATVEC + PUSH slot d, 28 + d MATVEC + POPMUL slot d (d < 4).
+8 + d PUSH slot d, 12 + d TIP_SET + POPMUL slot d, 16 + d POPMUL slot d, 20 + d TIP_SET + PUSH slot d,
+24 + d MATVEC + PUSH slot d, 28 + d MATVEC + POPMUL slot d (d < 4).
 
 Registers (all named in the clobber list of the asm statement):
   v[24:31] xA  v[32:39] xB   vectors under construction (site A = lane's first site, site B = HALF sites further)
@@ -104,6 +105,24 @@ def popmul(d):
     return out
 
 
+def setpop(d):
+    """x = prefetched value o slot d (TIP_SET followed by POPMUL: no copy of the value)"""
+    out = []
+    for i in range(4):
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XA + 2 * i), pair(PA + 2 * i), pair(slot_regs(d, 0)[i])))
+        out.append("v_mul_f64 %s, %s, %s" % (pair(XB + 2 * i), pair(PB + 2 * i), pair(slot_regs(d, 1)[i])))
+    return out
+
+
+def setpush(d):
+    """slot d = prefetched value (TIP_SET followed by PUSH: the vector under construction is dead after a PUSH)"""
+    out = []
+    for i in range(4):
+        out.append("v_mov_b64 %s, %s" % (pair(slot_regs(d, 0)[i]), pair(PA + 2 * i)))
+        out.append("v_mov_b64 %s, %s" % (pair(slot_regs(d, 1)[i]), pair(PB + 2 * i)))
+    return out
+
+
 def scale():
     out = []
     for (x, tmp, esc) in ((XA, 80, 78), (XB, 81, 79)):
@@ -128,7 +147,9 @@ def handlers():
     h[7] = ["s_branch .Ldone_%="]
     for d in range(4):
         h[8 + d] = push(d) + RET
+        h[12 + d] = ["s_waitcnt lgkmcnt(0)"] + setpop(d) + tipnext() + RET
         h[16 + d] = popmul(d) + RET
+        h[20 + d] = ["s_waitcnt lgkmcnt(0)"] + setpush(d) + tipnext() + RET
         h[24 + d] = matvec(slot_regs(d, 0), slot_regs(d, 1)) + RET
         h[28 + d] = matvec() + popmul(d) + RET
     return h
@@ -180,9 +201,13 @@ def emit():
             ins([".p2align 9"])
         ins(h.get(idx, RET))
     ins([".p2align 9", ".Ldone_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
-    for i in range(4):
-        ins(["v_mov_b32 %%[a%dl], v%d" % (i, XA + 2 * i), "v_mov_b32 %%[a%dh], v%d" % (i, XA + 2 * i + 1),
-             "v_mov_b32 %%[b%dl], v%d" % (i, XB + 2 * i), "v_mov_b32 %%[b%dh], v%d" % (i, XB + 2 * i + 1)])
+    # root dot product lh = w . x as one fma chain (weights 1 for no prior, 1/4 for the uniform prior: the same bits as the
+    # plain sum and the scaled sum), so that only lh and the exponent leave the statement
+    for (x, t) in ((XA, TA), (XB, TB)):
+        ins(["v_mul_f64 %s, %%[w0], %s" % (pair(t), pair(x))])
+        for i in range(1, 4):
+            ins(["v_fma_f64 %s, %%[w%d], %s, %s" % (pair(t), i, pair(x + 2 * i), pair(t))])
+    ins(["v_mov_b32 %%[al], v%d" % TA, "v_mov_b32 %%[ah], v%d" % (TA + 1), "v_mov_b32 %%[bl], v%d" % TB, "v_mov_b32 %%[bh], v%d" % (TB + 1)])
     ins(["v_mov_b32 %[ea], v78", "v_mov_b32 %[eb], v79", "s_nop 1"])
     return L
 
