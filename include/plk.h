@@ -231,7 +231,9 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
                                two sites per lane (k_ll_fused4_v4) on 1536-site tiles, or 1024-site tiles when the
                                tables leave less LDS, else one site per lane; 5 / 6: two sites per lane on 1024 / 1536
                                sites; 2 / 3: one site per lane (k_ll_fused4_asm_pt) on 1024 / 512 sites; 0: the round-2
-                               interpreter over 256-site tiles, no pair tables */ };
+                               interpreter over 256-site tiles, no pair tables */,
+       PLK_OPT_VEC_REG_STACK = 7 /* 1 (default): the vector kernels (9 <= k <= 20) keep the three busiest stack slots in
+                               registers (2 waves per SIMD); 0: every waiting vector goes through HBM slots (round 2) */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

@@ -27,6 +27,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <utility>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -135,7 +136,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1, opt_vec_reg_stack = 1;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0, info_ll_exec_flops = 0;
 };
 
@@ -1204,6 +1205,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_UP_NODES) { h->opt_up_nodes = value; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
+    if (option == PLK_OPT_VEC_REG_STACK) { h->opt_vec_reg_stack = value; return PLK_OK; }
     if (option == PLK_OPT_PAIR_TABLES) { h->opt_pair_tables = value; h->fmt_dirty = true; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
     return PLK_E_ARG;
@@ -1713,6 +1715,21 @@ static int build_tables(plk_engine *h, long kind)
     return PLK_OK;
 }
 
+/* the window of three stack slots that takes most pushes (register stack of the vector kernels) */
+static int vec_reg_window(const plk_engine *h)
+{
+    std::vector<long> per_slot(std::max(h->slots_needed, 1), 0);
+    for (const plk_op2 &o : h->ops) if ((o.x & 0xff) == OP_PUSH && o.y < (int)per_slot.size()) per_slot[o.y]++;
+    long best = -1;
+    int lo_best = 0;
+    for (int lo = 0; lo + 3 <= std::max(h->slots_needed, 3); lo++) {
+        long cnt = 0;
+        for (int q = lo; q < lo + 3 && q < (int)per_slot.size(); q++) cnt += per_slot[q];
+        if (cnt > best) { best = cnt; lo_best = lo; }
+    }
+    return lo_best;
+}
+
 template <int D, int NS>
 static void launch_fused(plk_engine *h, const FusedArgs &a, unsigned grid, size_t lds)
 {
@@ -1843,7 +1860,12 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.obs_nodes = h->d_obs_nodes; a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row; a.second_row = h->vec_second_row;
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
         a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
-        if (K == 16) hipLaunchKernelGGL(k_ll_vec<16>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        /* register stack (PLK_OPT_VEC_REG_STACK, default on): the window of three slots that takes most pushes */
+        const bool rs = h->opt_vec_reg_stack && K <= 20 && h->slots_needed >= 1;
+        a.reg_lo = rs ? vec_reg_window(h) : 0;
+        if (rs && K == 16) hipLaunchKernelGGL((k_ll_vec_rs<16, 3>), dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        else if (rs) hipLaunchKernelGGL((k_ll_vec_rs<20, 3>), dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
+        else if (K == 16) hipLaunchKernelGGL(k_ll_vec<16>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         else if (K == 20) hipLaunchKernelGGL(k_ll_vec<20>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         else hipLaunchKernelGGL(k_ll_vec<32>, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, a);
         h->info_ll_kernel = 4;
@@ -2130,16 +2152,18 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
 
     /* site-summed marginals without per-site output: the up pass leaves per-wave sums (MVS) instead of the N k planes */
     const bool msum_only = marg && !site_out && sums_out && !deriv;
-    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)nslots_m * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (msum_only ? ((size_t)N * k + 15) / 16 : (size_t)N * k) : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(nie + 2 * (size_t)nin) * C * R * 4 + (size_t)nslots_m * R * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg && !msum_only ? (size_t)N * k : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
     budget += h->work_cap * sizeof(double);
-    long chunk = (long)std::min<size_t>((size_t)((S + MF_SITES - 1) / MF_SITES * MF_SITES), budget / per_site);
+    long chunk = (long)std::min<size_t>((size_t)((S + MF_SITES - 1) / MF_SITES * MF_SITES), budget / (per_site + (msum_only ? ((size_t)N * h->k / 64 + 1) * sizeof(double) : 0)));
     if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
     chunk = chunk / MF_SITES * MF_SITES;
     if (chunk < MF_SITES) { cleanup(); h->err = "plk_deriv/plk_marginal: not enough device memory"; return PLK_E_NOMEM; }
-    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
+    /* site-summed marginals: one weighted sum per wave, node and state (sized for a whole chunk) */
+    const size_t mvs_doubles = msum_only ? (size_t)N * k * (size_t)((chunk + MF_SITES - 1) / MF_SITES) * (MF_BLOCK / 64) : 0;
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk + mvs_doubles))) { cleanup(); return rc; }
 
     std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
     for (long s0 = 0; s0 < S; s0 += chunk) {
@@ -2304,16 +2328,17 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
     const bool msum_only = marg && !site_out && sums_out && !deriv;      /* per-wave sums instead of the N x 4 planes */
-    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? ER : 0) + (marg ? (msum_only ? ((size_t)N * 4 + 63) / 64 : (size_t)N * 4) : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * 4 + (size_t)(nsc + 2) * C + 1 + (deriv ? ER : 0) + (marg && !msum_only ? (size_t)N * 4 : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
     budget += h->work_cap * sizeof(double);
-    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / (per_site + (msum_only ? ((size_t)N * h->k / 64 + 1) * sizeof(double) : 0)));
     if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
     if (chunk < 1) { cleanup(); h->err = "plk_deriv/plk_marginal: not enough device memory for one site"; return PLK_E_NOMEM; }
     if (chunk < S) chunk = std::max<long>(UD4_BLOCK, chunk / UD4_BLOCK * UD4_BLOCK);
-    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) { cleanup(); return rc; }
+    const size_t mvs_doubles = msum_only ? (size_t)N * 4 * (size_t)((chunk + UD4_BLOCK - 1) / UD4_BLOCK) * (UD4_BLOCK / 64) : 0;   /* per-wave marginal sums */
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk + mvs_doubles))) { cleanup(); return rc; }
 
     std::vector<long double> dsum(deriv ? ER : 0, 0.0L), msum(marg ? (size_t)N * 4 : 0, 0.0L);
     for (long s0 = 0; s0 < S; s0 += chunk) {
@@ -2458,16 +2483,17 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     if (hipGetLastError() != hipSuccess) { h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
     const bool msum_only = marg && !site_out && sums_out && !deriv;      /* per-wave sums instead of the N x k planes */
-    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * K + (size_t)nslots * K + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg ? (msum_only ? ((size_t)N * k + 63) / 64 : (size_t)N * k) : 0)) * sizeof(double);
+    const size_t per_site = ((size_t)(2 * (size_t)nin) * C * K + (size_t)nslots * K + (size_t)(nsc + 2) * C + 1 + (deriv ? E : 0) + (marg && !msum_only ? (size_t)N * k : 0)) * sizeof(double);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t budget = free_b > (size_t)(6ull << 30) ? free_b - (size_t)(4ull << 30) : free_b / 2;
     budget += h->work_cap * sizeof(double);
-    long chunk = (long)std::min<size_t>((size_t)S, budget / per_site);
+    long chunk = (long)std::min<size_t>((size_t)S, budget / (per_site + (msum_only ? ((size_t)N * h->k / 64 + 1) * sizeof(double) : 0)));
     if (h->opt_site_chunk > 0) chunk = std::min<long>(chunk, h->opt_site_chunk);
     if (chunk < 1) { h->err = "plk_deriv/plk_marginal: not enough device memory for one site"; return PLK_E_NOMEM; }
     if (chunk < S) chunk = std::max<long>(UDV_BLOCK, chunk / UDV_BLOCK * UDV_BLOCK);
-    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk))) return rc;
+    const size_t mvs_doubles = msum_only ? (size_t)N * k * (size_t)((chunk + UDV_BLOCK - 1) / UDV_BLOCK) * (UDV_BLOCK / 64) : 0;   /* per-wave marginal sums */
+    if ((rc = dev_reserve(h, &h->d_work, &h->work_cap, per_site / sizeof(double) * (size_t)chunk + mvs_doubles))) return rc;
 
     std::vector<long double> dsum(deriv ? E : 0, 0.0L), msum(marg ? (size_t)N * k : 0, 0.0L);
     for (long s0 = 0; s0 < S; s0 += chunk) {
@@ -2479,6 +2505,7 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         a.first_slot = ch.first_slot; a.first_row = ch.first_row; a.second_row = ch.second_row;
         a.PT = d_PT; a.tip = d_tipv; a.dtip = d_dtipv; a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w;
         a.visits = b + o_vis; a.nvisits = uv.nvisits; a.MS = d_MS; a.nstream = nstream;
+        a.reg_lo = vec_reg_window(h);
         double *p = h->d_work;
         a.LN = p; p += (size_t)nin * C * K * n;
         a.FN = p; p += (size_t)nin * C * K * n;

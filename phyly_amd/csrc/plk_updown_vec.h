@@ -50,6 +50,7 @@ struct UpVecArgs {
     int nstream;
     double *LN, *FN;               /* [(ent*C + c)][K][n] */
     double *slots;                 /* [slot][K][n] */
+    int reg_lo;                    /* k_down_vec_rs: stack slots reg_lo .. reg_lo + 2 live in accumulation registers */
     double *SC, *CW, *XC;          /* as Up4Args */
     double *LH, *DV, *MV;          /* [n], [E][n], [N][k][n] */
     double *MVS;                   /* site-summed marginals only: [(node * k + state)][nwaves] per-wave weighted sums, MV unused */
@@ -104,9 +105,13 @@ __device__ __forceinline__ bool udv_const(const double (&x)[K], int k)
     return diff == 0;
 }
 /* ---------------------------------------------------------------------------------------------------------- */
-template <int K>
-__global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *__restrict__ obs_nodes)
+template <int K, int NREG>
+__device__ __forceinline__ void k_down_vec_body(const UpVecArgs &a, const int *__restrict__ obs_nodes)
 {
+    if constexpr (NREG > 0) {
+        static_assert(2 * NREG * K <= 128, "register stack: accumulation registers a0..a127");
+        asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);     /* the kernel owns a0..a127 (see k_ll_vec_rs) */
+    }
     const long sl = (long)blockIdx.x * UDV_BLOCK + threadIdx.x;
     const bool valid = sl < a.n;
     const long slc = valid ? sl : a.n - 1;
@@ -162,6 +167,16 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
                 if (!wrap || c + 1 < a.C)
                     udv_gather<K>(tipc + (size_t)wrap * tabc + ((size_t)(oz & 0x3fffffff) * a.nchar + code_next) * K, nv);
                 code_next = a.codes[(size_t)obs[oy] * a.Spad + sg];
+            } else if (NREG > 0 && code == OP_PUSH && oy - a.reg_lo >= 0 && oy - a.reg_lo < NREG) {
+                const int r = oy - a.reg_lo;
+                if (r == 0) vec_acc_push<0, K>(cur, std::make_integer_sequence<int, K>());
+                else if (NREG > 1 && r == 1) vec_acc_push<(NREG > 1 ? 1 : 0), K>(cur, std::make_integer_sequence<int, K>());
+                else vec_acc_push<(NREG > 2 ? 2 : 0), K>(cur, std::make_integer_sequence<int, K>());
+            } else if (NREG > 0 && code == OP_POPMUL && oy - a.reg_lo >= 0 && oy - a.reg_lo < NREG) {
+                const int r = oy - a.reg_lo;
+                if (r == 0) vec_acc_popmul<0, K>(cur, std::make_integer_sequence<int, K>());
+                else if (NREG > 1 && r == 1) vec_acc_popmul<(NREG > 1 ? 1 : 0), K>(cur, std::make_integer_sequence<int, K>());
+                else vec_acc_popmul<(NREG > 2 ? 2 : 0), K>(cur, std::make_integer_sequence<int, K>());
             } else if (code == OP_PUSH) {
                 if (valid) udv_store<K>(a.slots + (size_t)oy * K * n, n, slc, cur);
             } else if (code == OP_POPMUL) {
@@ -205,6 +220,14 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
         a.LH[sl] = lh_total;
     }
 }
+
+template <int K>
+__global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *__restrict__ obs_nodes) { k_down_vec_body<K, 0>(a, obs_nodes); }
+
+/* (A register-stack variant like k_ll_vec_rs was built for this pass in round 3 and dropped: with the prefetched tip row
+ * (K register pairs) live next to cur and acc the compiler itself spills into accumulation registers, which the explicit
+ * AGPR stack cannot share -- tools/isa_lint.py refuses the build -- and the ll kernel's variant gained only 4 %:
+ * profiles/r03_exp_aa_kernel_variants.json.  k_down_vec_body keeps the NREG parameter for a two-sites-per-lane follow-up.) */
 
 /*
  * Up pass.  visits: for every internal node in BFS order

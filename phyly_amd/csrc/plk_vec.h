@@ -30,6 +30,7 @@ struct VecArgs {
     const uint8_t *codes;     /* [N][Spad] */
     const double *cat_prior, *root_w, *w;
     double *slots;            /* [nslots][K][S] */
+    int reg_lo;               /* NREG > 0: stack slots reg_lo .. reg_lo + NREG - 1 live in registers, the others in `slots` */
     double *site_ll;
     dd *partial;
 };
@@ -69,9 +70,31 @@ __device__ __forceinline__ void vec_touch(const PLK_AS4 double *p)
 
 #include "plk_vec_matvec_asm.h"   /* vec_matvec<K>: the product itself, explicit SGPR banks for K = 16, 20 */
 
-template <int K>
-__global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
+/* NREG: stack slots kept in registers (round 3).  With every waiting vector in HBM the kernel moved 22 GB per million
+ * sites at BASELINE config 4 (70 pushes and pops of 160 bytes per site and category, 3.5 TB/s: it was bound by that
+ * stream, not by arithmetic).  NREG = 3 keeps the three busiest of the tree's four slots on chip (K register pairs each,
+ * 2 waves per SIMD instead of 4); the remaining slot still goes through `slots`. */
+/* slot Q of the register stack = accumulation registers a[2 Q K .. 2 (Q + 1) K - 1], moved with explicit
+ * v_accvgpr_write / read (acc_write / acc_read of plk_fused4.h); tools/isa_lint.py checks that the compiler itself
+ * leaves the accumulation registers of these kernels alone */
+template <int Q, int K, int... I>
+__device__ __forceinline__ void vec_acc_push(const double (&cur)[K], std::integer_sequence<int, I...>)
 {
+    (acc_write<Q * K + I>(cur[I]), ...);
+}
+template <int Q, int K, int... I>
+__device__ __forceinline__ void vec_acc_popmul(double (&cur)[K], std::integer_sequence<int, I...>)
+{
+    ((cur[I] *= acc_read<Q * K + I>()), ...);
+}
+
+template <int K, int NREG>
+__device__ __forceinline__ void k_ll_vec_body(const VecArgs &a)
+{
+    if constexpr (NREG > 0) {
+        static_assert(2 * NREG * K <= 128, "register stack: accumulation registers a0..a127");
+        asm volatile("" ::: PLK_CLOBBER_A0_31, PLK_CLOBBER_A32_63, PLK_CLOBBER_A64_127);     /* the kernel owns a0..a127 */
+    }
     const int tid = threadIdx.x;
     const long s = (long)blockIdx.x * VEC_BLOCK + tid;
     const bool valid = s < a.S;
@@ -122,6 +145,16 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
                     for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] *= v.x; cur[i + 1] *= v.y; }
                 }
                 code_next = a.codes[(size_t)obs[ow] * a.Spad + sc];
+            } else if (NREG > 0 && code == OP_PUSH && oy - a.reg_lo >= 0 && oy - a.reg_lo < NREG) {
+                const int r = oy - a.reg_lo;
+                if (r == 0) vec_acc_push<0, K>(cur, std::make_integer_sequence<int, K>());
+                else if (NREG > 1 && r == 1) vec_acc_push<(NREG > 1 ? 1 : 0), K>(cur, std::make_integer_sequence<int, K>());
+                else vec_acc_push<(NREG > 2 ? 2 : 0), K>(cur, std::make_integer_sequence<int, K>());
+            } else if (NREG > 0 && code == OP_POPMUL && oy - a.reg_lo >= 0 && oy - a.reg_lo < NREG) {
+                const int r = oy - a.reg_lo;
+                if (r == 0) vec_acc_popmul<0, K>(cur, std::make_integer_sequence<int, K>());
+                else if (NREG > 1 && r == 1) vec_acc_popmul<(NREG > 1 ? 1 : 0), K>(cur, std::make_integer_sequence<int, K>());
+                else vec_acc_popmul<(NREG > 2 ? 2 : 0), K>(cur, std::make_integer_sequence<int, K>());
             } else if (code == OP_PUSH) {
                 /* plane base pinned in SGPRs, the lane's site as a 32-bit offset: otherwise the compiler keeps K 64-bit
                  * lane addresses live across the loop (40 VGPRs at K = 20, a wave of occupancy) */
@@ -172,6 +205,13 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a)
         if (tid == 0) a.partial[blockIdx.x] = r;
     }
 }
+
+template <int K>
+__global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a) { k_ll_vec_body<K, 0>(a); }
+
+/* the register-stack variant: 2 waves per SIMD (256 registers per lane) */
+template <int K, int NREG>
+__global__ __launch_bounds__(VEC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ll_vec_rs(VecArgs a) { k_ll_vec_body<K, NREG>(a); }
 
 /* tip[((c*(ntips+1) + t)*nchar + code)*K + i] = (P_e defs[code])[i] in double-double (exact for constant
  * definition rows, src/util.c:276-283); slot ntips (edge -1) holds defs[code] itself; entries i >= k are 0

@@ -22,7 +22,7 @@ import sys
 NO_DST = ("s_cmp", "s_branch", "s_cbranch", "s_waitcnt", "s_nop", "s_setpc", "s_endpgm", "s_barrier", "s_sleep",
           "s_bitcmp", "s_setprio", "s_sethalt", "s_trap", "s_dcache", "s_icache", "s_store", "s_buffer_store",
           "s_setreg", "s_set_gpr", "s_cbranch", "s_code_end", "s_waitcnt_depctr", "s_incperflevel", "s_decperflevel")
-AGPR_KERNELS = re.compile(r"k_ll_fused4|k_down_fused4")
+AGPR_KERNELS = re.compile(r"k_ll_fused4|k_down_fused4|k_ll_vec_rs|k_down_vec_rs")
 
 
 def sgprs(tok):
