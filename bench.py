@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--categories", type=int, default=0, help="override the number of Gamma categories (experiments; not the metric's workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (nccl) and all-reduce also when launched as one process")
+    ap.add_argument("--torch-allreduce", action="store_true", help="N > 1: torch.distributed.all_reduce instead of the engine's own RCCL call")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: block the compute stream on every all-reduce (no overlap with the next step)")
     ap.add_argument("--deriv-steps", type=int, default=3, help="steps of the edge-gradient leg (0 = skip)")
     ap.add_argument("--deriv-sites", type=int, default=0, help="sites per GPU of the edge-gradient leg (default: min(block, 2M))")
@@ -244,6 +245,33 @@ def main():
     # evaluations are independent, nothing in step i + 1 reads the reduced sum of step i.  Every step still does its
     # one all-reduce; all of them are waited for before the clock stops.  --sync-allreduce blocks the compute stream on
     # each reduction instead (the latency-exposed figure; DESIGN.md section 5 quotes both).
+    # N > 1: the reduction step.  Default: RCCL called by the engine itself on the stream its kernels run on
+    # (plk_allreduce_sum_async, include/plk.h: one C call per step, no framework work object, no second stream); the RCCL
+    # id travels over torch.distributed once, and a test reduction is compared with torch's before the path is trusted.
+    # If anything in that fails on any rank, every rank falls back to torch.distributed.all_reduce (--torch-allreduce
+    # forces it).
+    native = False
+    if use_dist and not args.torch_allreduce:
+        ok = 1
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt = torch.tensor(list(E.Engine.comm_unique_id()), dtype=torch.uint8, device=dev)
+            dist.broadcast(idt, 0)
+            eng.comm_init(world, rank, bytes(idt.cpu().tolist()))
+            t1 = torch.tensor([rank + 1.0, 0.5], dtype=torch.float64, device=dev)
+            t2 = t1.clone()
+            eng.allreduce_sum_async(t1.data_ptr(), 2)
+            dist.all_reduce(t2, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            if not torch.equal(t1, t2):
+                ok = 0
+        except Exception as exc:          # noqa: BLE001 -- any failure means "use the framework's collective"
+            sys.stderr.write("bench.py: native RCCL reduction unavailable on rank %d (%s); using torch.distributed\n" % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native = bool(flag.item())
     RING = 4
     red = torch.zeros((RING, 2), dtype=torch.float64, device=dev)
     pending = []
@@ -256,7 +284,9 @@ def main():
             pending.pop(0).wait()                      # the slot about to be rewritten has been reduced
         eng.update_edge_rates(wl.edge_rates_csr)       # new rates: K1 (+ stream + tables) runs again
         eng.ll_async(sum_device_ptr=red[i].data_ptr()) # {hi, lo} of this rank's block, left on the device
-        if use_dist:
+        if use_dist and native:
+            eng.allreduce_sum_async(red[i].data_ptr(), 2)
+        elif use_dist:
             if args.sync_allreduce:
                 dist.all_reduce(red[i], op=dist.ReduceOp.SUM)
             else:
@@ -406,6 +436,7 @@ def main():
                        "total_sites": S_total, "sites_per_gpu": S, "states": wl.k, "categories": wl.prepare()["C"], "taxa": wl.T,
                        "parallelism": "site-shard x%d" % world},
             "ll_sum": total,
+            "allreduce": ("rccl, queued by the engine on its stream" if native else "torch.distributed (nccl)") if use_dist else None,
             "step_minus_kernel_ms": dt / args.steps * 1e3 - kern_s * 1e3,
             "roofline": roofline,
         }

@@ -193,6 +193,22 @@ int plk_fit_edge_rates(plk_engine *h, int method, int max_iter, double ftol, con
  */
 int plk_hess(plk_engine *h, double *hess_sums_out);
 
+/*
+ * One process per GPU: the reduction step of the site-sharded path on RCCL, issued from the engine.
+ * Sites are independent given (tree, Q, rates); every rank evaluates its block of site patterns and the only exchange
+ * is the sum of the aggregated outputs (src/ndaccum.c:198-254 is the reference's only cross-site step): 2 doubles for
+ * ll, 2E for edge gradients, 2Nk for site-summed marginals, always {hi, lo} words.  The engine loads the RCCL the
+ * process already has (librccl.so.1; no link-time dependency) and queues ncclAllReduce on its own stream, behind the
+ * kernels that produce the sums -- no framework call per step.
+ *   plk_comm_unique_id   rank 0 makes the 128-byte id; the caller hands it to the other ranks (torch.distributed, MPI, a file)
+ *   plk_comm_init        collective: every rank calls it with the same id
+ *   plk_allreduce_sum_async  in-place sum over ranks of `count` doubles in DEVICE memory, queued on the engine's stream
+ */
+int plk_comm_unique_id(unsigned char id_out[128]);
+int plk_comm_init(plk_engine *h, int nranks, int rank, const unsigned char id[128]);
+int plk_allreduce_sum_async(plk_engine *h, double *dev, long count);
+int plk_comm_destroy(plk_engine *h);
+
 /* Introspection for tests and profiling. */
 int plk_get_transition_matrices(plk_engine *h, double *P_out /* [C][E][k][k] host */);
 int plk_get_info(plk_engine *h, int what, long *out);

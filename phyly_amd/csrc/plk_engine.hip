@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <set>
 #include <string>
@@ -137,10 +138,50 @@ struct plk_engine {
 
     /* options / info */
     long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1, opt_vec_reg_stack = 1;
+    void *comm = nullptr;                /* ncclComm_t of the one-process-per-GPU reduction step */
+    int comm_ranks = 0;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0, info_ll_exec_flops = 0;
 };
 
 static std::string g_create_error;
+
+/* RCCL is taken from the process at run time (the framework's copy when there is one): no link-time dependency, and a
+ * process that never calls plk_comm_* never touches it */
+struct PlkNcclId { char internal[128]; };
+struct PlkRccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ PlkNcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+static PlkRccl g_rccl;
+static std::mutex g_rccl_mu;
+
+static bool rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    void *lib = nullptr;
+    for (const char *n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     /* the copy already in the process */
+    for (const char *n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { g_rccl.err = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return false; }
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void **, int, PlkNcclId, int)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(lib, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) { g_rccl.err = "RCCL: entry points missing"; return false; }
+    g_rccl.lib = lib;
+    return true;
+}
+
+static std::string rccl_text(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : ("code " + std::to_string(rc)); }
+
+
 
 /* Live engine handles.  Every entry point refuses a handle that plk_create did not return or that plk_destroy has
  * already taken (PLK_E_ARG instead of a use after free); plk_destroy of such a handle is a no-op.  Once the process
@@ -1180,6 +1221,7 @@ extern "C" void plk_destroy(plk_engine *h)
         if (g_exiting || !g_live.erase(h)) return;
     }
     (void)hipSetDevice(h->device);
+    if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     void *ptrs[] = {h->d_indptr, h->d_indices, h->d_preorder, h->d_Qn, h->d_edge_rates, h->d_cat_rates,
                     h->d_cat_prior, h->d_root_w, h->d_Pdd, h->d_P, h->d_dP, h->d_scratch, h->d_codes,
                     h->d_defs, h->d_B, h->d_w, h->d_ops, h->d_fops, h->d_words, h->d_mat_edge, h->d_edge_slot, h->d_op_edge, h->d_tip_edge, h->d_obs_nodes,
@@ -2660,6 +2702,57 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
             sums_out[2 * r] = hi;
             sums_out[2 * r + 1] = (double)(src[r] - (long double)hi);
         }
+    }
+    return PLK_OK;
+}
+
+/* ====================================================================== */
+/* X1: the reduction step over ranks on RCCL (one process per GPU)         */
+/* ====================================================================== */
+
+extern "C" int plk_comm_unique_id(unsigned char id_out[128])
+{
+    if (!id_out) return PLK_E_ARG;
+    if (!rccl_load()) { g_create_error = g_rccl.err; return PLK_E_UNSUPPORTED; }
+    PlkNcclId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc) { g_create_error = "ncclGetUniqueId: " + rccl_text(rc); return PLK_E_DEVICE; }
+    memcpy(id_out, id.internal, 128);
+    return PLK_OK;
+}
+
+extern "C" int plk_comm_init(plk_engine *h, int nranks, int rank, const unsigned char id[128])
+{
+    if (!plk_live(h) || !id || nranks < 1 || rank < 0 || rank >= nranks) return PLK_E_ARG;
+    if (!rccl_load()) { h->err = g_rccl.err; return PLK_E_UNSUPPORTED; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    PlkNcclId nid;
+    memcpy(nid.internal, id, 128);
+    const int rc = g_rccl.CommInitRank(&h->comm, nranks, nid, rank);
+    if (rc) { h->comm = nullptr; h->err = "ncclCommInitRank: " + rccl_text(rc); return PLK_E_DEVICE; }
+    h->comm_ranks = nranks;
+    return PLK_OK;
+}
+
+extern "C" int plk_allreduce_sum_async(plk_engine *h, double *dev, long count)
+{
+    if (!plk_live(h) || !dev || count < 1) return PLK_E_ARG;
+    if (!h->comm) { h->err = "plk_allreduce_sum_async: plk_comm_init first"; return PLK_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = g_rccl.AllReduce(dev, dev, (size_t)count, /* ncclDouble */ 8, /* ncclSum */ 0, h->comm, h->stream);
+    if (rc) { h->err = "ncclAllReduce: " + rccl_text(rc); return PLK_E_DEVICE; }
+    return PLK_OK;
+}
+
+extern "C" int plk_comm_destroy(plk_engine *h)
+{
+    if (!plk_live(h)) return PLK_E_ARG;
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
     }
     return PLK_OK;
 }

@@ -66,6 +66,10 @@ def load_library():
     lib.plk_get_transition_matrices.argtypes = [vp, vp]
     lib.plk_get_info.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.plk_set_option.argtypes = [vp, ci, cl]
+    lib.plk_comm_unique_id.argtypes = [vp]
+    lib.plk_comm_init.argtypes = [vp, ci, ci, vp]
+    lib.plk_allreduce_sum_async.argtypes = [vp, vp, cl]
+    lib.plk_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -250,6 +254,26 @@ class Engine:
         P = np.empty((self.C, self.E, self.k, self.k))
         self._check(self._lib.plk_get_transition_matrices(self._h, _ptr(P)))
         return P
+
+    # -- one process per GPU: the reduction step on RCCL, queued by the engine on its own stream (include/plk.h)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (bytes); made on rank 0 and handed to the other ranks by the caller"""
+        lib = load_library()
+        buf = (ctypes.c_ubyte * 128)()
+        if lib.plk_comm_unique_id(buf):
+            raise EngineError(lib.plk_create_error().decode())
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.plk_comm_init(self._h, int(nranks), int(rank), buf))
+
+    def allreduce_sum_async(self, device_ptr, count):
+        self._check(self._lib.plk_allreduce_sum_async(self._h, ctypes.c_void_p(int(device_ptr)), int(count)))
+
+    def comm_destroy(self):
+        self._check(self._lib.plk_comm_destroy(self._h))
 
     def info(self, what):
         v = ctypes.c_long()
