@@ -2309,9 +2309,36 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
             if (all_leaves) node_inline[b] = 1;
         }
     }
+    /* derivative queries proper (edge form dP, no marginals, at most 4 rate categories; the expectation queries keep k_up4,
+     * whose several-forms-per-pass variant they must agree with bit for bit): node-visit up pass k_up4_nodes, which
+     * keeps the vector of a continued child in registers for all categories; PLK_OPT_UP_NODES bit 1 switches it off */
+    const bool nodes4 = deriv && !marg && nM == 1 && dzero && C <= 4 && E > 0 && (h->opt_up_nodes & 2);
+    /* Pair messages (round 3): a node whose two children are leaves, without data of its own, sends its parent one of
+     * nchar^2 vectors P_a (P_b B_b o P_c B_c).  With the node-visit up pass those come from a table (k_build_tables_pt, the
+     * ll kernels' pair tables), so the down pass does not store L_a and the up pass does not read it: a third of the
+     * down pass's writes and a fifth of the up pass's reads at BASELINE config 3. */
+    std::vector<int> pair_of(N, -1), pair_tabs;
+    std::vector<char> skip_l(N, 0);
+    int npairs4 = 0;
+    if (nodes4 && h->nchar <= 16 && h->opt_pair_tables) {
+        if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+        std::vector<int> t_unit, t_edge, t_eb, t_ec;
+        for (int b = 0; b < N; b++) {
+            const int e0 = h->indptr[b];
+            if (h->indptr[b + 1] - e0 != 2 || h->b_to_idx[b] < 0 || h->node_has_data[b]) continue;
+            if (edge_tip[e0] < 0 || edge_tip[e0 + 1] < 0) continue;
+            pair_of[b] = npairs4; skip_l[b] = 1;
+            t_unit.push_back(npairs4 * h->nchar); t_edge.push_back(h->b_to_idx[b]); t_eb.push_back(e0); t_ec.push_back(e0 + 1);
+            npairs4++;
+        }
+        pair_tabs = t_unit;
+        pair_tabs.insert(pair_tabs.end(), t_edge.begin(), t_edge.end());
+        pair_tabs.insert(pair_tabs.end(), t_eb.begin(), t_eb.end());
+        pair_tabs.insert(pair_tabs.end(), t_ec.begin(), t_ec.end());
+    }
     /* down-pass program: observation ops carry their staged code row and the (slot, row) of the next one */
     PlkChain ch2;
-    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch2);
+    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch2, npairs4 ? skip_l.data() : nullptr);
     const int nobs2 = (int)h->obs_nodes.size();
     {
         const int D2 = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : (h->slots_needed <= 16 ? 16 : INT_MAX));
@@ -2320,20 +2347,17 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     }
     const std::vector<plk_op4> &ops2 = ch2.ops;
     const int first_slot2 = ch2.first_slot, first_row2 = ch2.first_row;
-    /* derivative queries proper (edge form dP, no marginals, at most 4 rate categories; the expectation queries keep k_up4,
-     * whose several-forms-per-pass variant they must agree with bit for bit): node-visit up pass k_up4_nodes, which
-     * keeps the vector of a continued child in registers for all categories; PLK_OPT_UP_NODES bit 1 switches it off */
-    const bool nodes4 = deriv && !marg && nM == 1 && dzero && C <= 4 && E > 0 && (h->opt_up_nodes & 2);
     PlkUpNodes un4;
     if (nodes4) {
         if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
         plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                           node_int.data(), node_scale.data(), edge_mask, un4);
-        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc);
+                           node_int.data(), node_scale.data(), edge_mask, un4, npairs4 ? pair_of.data() : nullptr);
+        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc, npairs4, edge_tip.data());
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
-    const int *d_vis4 = nullptr;
-    double *d_tip4 = nullptr, *d_dtip4 = nullptr;
+    const int *d_vis4 = nullptr, *d_ptabs = nullptr;
+    double *d_tip4 = nullptr, *d_dtip4 = nullptr, *d_ptab4 = nullptr;
+    size_t nptab = 0;
     auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * 4;
     {
@@ -2349,8 +2373,10 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         const size_t o_inl = put(node_inline.data(), (size_t)N);
         const size_t o_em = edge_mask && E > 0 ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
         const size_t o_vis = nodes4 ? put(un4.rec.data(), un4.rec.size()) : 0;
+        const size_t o_pt = npairs4 ? put(pair_tabs.data(), pair_tabs.size()) : 0;
+        nptab = (size_t)C * npairs4 * h->nchar * h->nchar * 4;
         if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4))) return rc;
-        if ((rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, ntab * (size_t)(1 + nM)))) return rc;
+        if ((rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, ntab * (size_t)(1 + nM) + nptab))) return rc;
         HIPCHK(h, hipMemcpyAsync(h->d_u4pack, pack.data(), pack.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));      /* pack is a local */
         int *b = h->d_u4pack;
@@ -2360,13 +2386,17 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         d_emask = edge_mask && E > 0 ? b + o_em : nullptr;
         d_nmask = node_mask ? b + o_nm : nullptr;
         d_vis4 = nodes4 ? b + o_vis : nullptr;
-        d_tip4 = h->d_u4tip; d_dtip4 = h->d_u4tip + ntab;
+        d_ptabs = npairs4 ? b + o_pt : nullptr;
+        d_tip4 = h->d_u4tip; d_dtip4 = h->d_u4tip + ntab; d_ptab4 = h->d_u4tip + ntab * (size_t)(1 + nM);
     }
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
                        E, ntips + 1, h->nchar, d_te, h->d_Pdd, h->d_defs, d_tip4);
     for (int m = 0; m < nM; m++)
         hipLaunchKernelGGL(k_build_dtip4, dim3(ntips + 1, C), dim3(64), 0, h->stream,
                            E, ntips, h->nchar, d_te, d_M + (size_t)m * C * E * 16, h->d_defs, d_dtip4 + (size_t)m * ntab, dzero);
+    if (npairs4)       /* pair tables: [C][npairs * nchar units][nchar][4], the ll kernels' builder on a list of pairs only */
+        hipLaunchKernelGGL(k_build_tables_pt, dim3(npairs4, C), dim3(64), 0, h->stream,
+                           E, npairs4, npairs4 * h->nchar, h->nchar, d_ptabs, h->d_Pdd, h->d_defs, d_ptab4);
     if (hipGetLastError() != hipSuccess) { cleanup(); h->err = "plk_deriv/plk_marginal: table build failed"; return PLK_E_DEVICE; }
 
     const bool msum_only = marg && !site_out && sums_out && !deriv;      /* per-wave sums instead of the N x 4 planes */
@@ -2406,7 +2436,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.MV = p; a.MVS = nullptr; a.wsite = nullptr;
         if (marg && msum_only) { a.MVS = p; a.wsite = h->d_w ? h->d_w + s0 : nullptr; p += (size_t)N * 4 * nwv; }
         else if (marg) p += (size_t)N * 4 * n;
-        a.visits = d_vis4; a.nvisits = un4.nvisits;
+        a.visits = d_vis4; a.nvisits = un4.nvisits; a.ptab = npairs4 ? d_ptab4 : nullptr; a.npairs = npairs4;
         /* (the node-visit pass writes the row of every wanted edge: rows need clearing only under a mask) */
         if (deriv && E > 0 && !(nodes4 && !edge_mask)) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * 4 * nwv : (size_t)N * 4 * n) * sizeof(double), h->stream));

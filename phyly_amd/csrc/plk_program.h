@@ -816,7 +816,7 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
         } else if (code == OP_MATVEC && mode >= 1) {
             o.y = pg.op_edge[pc];
             o.z = node_int ? node_int[indices[o.y]] : 0;
-            if (mode == 3 && skip_store && skip_store[indices[o.y]]) o.z = -1;      /* this child's vector is not stored */
+            if ((mode == 3 || mode == 1) && skip_store && skip_store[indices[o.y]]) o.z = -1;      /* this child's vector is not stored */
             if (mode == 2) o.w = edge_int[o.y];
         } else if (code == OP_SCALE && mode >= 1 && node_scale) {
             o.y = node_scale[pg.ops[pc].y];
@@ -1022,16 +1022,20 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
  *                    storage index (internal child) or -1
  */
 enum { PLK_UN_OWN_D = 1, PLK_UN_FROM_REGS = 2 };                                              /* header flags */
-enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_POS_SHIFT = 4 };   /* child flags */
+enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_PAIR = 8, PLK_UN_POS_SHIFT = 4 };   /* child flags;
+   PLK_UN_PAIR: the child's message P_b L_b comes from pair table number `fifth field` (its two leaves' codes), L_b is not stored;
+   the record's fourth int then still holds the storage index (the child's own visit needs its G) */
 
 struct PlkUpNodes {
     std::vector<int> rec;
     int nvisits = 0;
 };
 
+/* pair_of: null, or N ints: index of the node's pair table (its message comes from the table, not from a stored L) or -1.
+ * A pair child's flags carry PLK_UN_PAIR and its tip-slot field holds -2 - pair (tip slots are >= 0, -1 = internal). */
 static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
                                       const int *edge_tip, const int *node_int, const int *node_scale, const int *edge_mask,
-                                      PlkUpNodes &un)
+                                      PlkUpNodes &un, const int *pair_of = nullptr)
 {
     un.rec.clear(); un.nvisits = 0;
     std::vector<int> edge_into(N, -1);
@@ -1069,7 +1073,8 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
                     if (leaf) fl = wanted(idx) ? PLK_UN_LEAF_D : 0;
                     else if (sub[b]) fl = j == cont ? PLK_UN_CONTINUE : PLK_UN_STORE_G;
                 }
-                const int cr[4] = {b, edge_tip[idx], fl | (j << PLK_UN_POS_SHIFT), leaf ? -1 : node_int[b]};
+                const bool pr = !leaf && pair_of && pair_of[b] >= 0;
+                const int cr[4] = {b, pr ? -2 - pair_of[b] : edge_tip[idx], fl | (pr ? PLK_UN_PAIR : 0) | (j << PLK_UN_POS_SHIFT), leaf ? -1 : node_int[b]};
                 un.rec.insert(un.rec.end(), cr, cr + 4);
             }
         un.nvisits++;
@@ -1082,7 +1087,7 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
 /* replays the kernel's walk: indices in range, every child position once, every G read after it was written (or
  * handed over in registers by the visit just before) */
 static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const int *ix, const PlkUpNodes &un, int nint_nodes, int ntips,
-                                             int nscale_slots)
+                                             int nscale_slots, int npairs = 0, const int *edge_tip = nullptr)
 {
     std::vector<char> g_written(std::max(nint_nodes, 1), 0), visited(N, 0);
     size_t vp = 0;
@@ -1105,9 +1110,17 @@ static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const 
         const int *ch = h + 8;
         std::vector<char> seen(deg, 0);
         for (int j = 0; j < deg; j++) {
-            const int b = ch[4 * j], t = ch[4 * j + 1], fl = ch[4 * j + 2] & ((1 << PLK_UN_POS_SHIFT) - 1), pos = ch[4 * j + 2] >> PLK_UN_POS_SHIFT, bi = ch[4 * j + 3];
+            const int b = ch[4 * j], fl = ch[4 * j + 2] & ((1 << PLK_UN_POS_SHIFT) - 1), pos = ch[4 * j + 2] >> PLK_UN_POS_SHIFT, bi = ch[4 * j + 3];
+            int t = ch[4 * j + 1];
             if (pos < 0 || pos >= deg || seen[pos]) return plk_fmt("up nodes: child positions of visit %ld", v);
             seen[pos] = 1;
+            if (fl & PLK_UN_PAIR) {
+                /* the message of this child is a pair-table row: two leaf children, table index in range */
+                const int pi = -2 - t;
+                if (pi < 0 || pi >= npairs || b < 0 || b >= N || ip[b + 1] - ip[b] != 2) return plk_fmt("up nodes: bad pair child in visit %ld", v);
+                if (edge_tip && (edge_tip[ip[b]] < 0 || edge_tip[ip[b] + 1] < 0)) return plk_fmt("up nodes: pair child with an internal child in visit %ld", v);
+                t = -1;
+            }
             if (b != ix[e0 + pos] || t < -1 || t >= ntips) return plk_fmt("up nodes: bad child in visit %ld", v);
             if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up nodes: bad storage index in visit %ld", v);
             if (t >= 0 && (fl & (PLK_UN_STORE_G | PLK_UN_CONTINUE))) return plk_fmt("up nodes: a leaf gets a stored vector in visit %ld", v);
@@ -1162,7 +1175,7 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
             do { nx = nx + 1 < nops ? nx + 1 : 0; } while ((pg.ops[nx].x & 0xff) != OP_MATVEC);
             if (o.z != nx) return plk_fmt("down program: op %ld names the wrong next product", pc);
         } else if (code == OP_MATVEC && mode >= 1) {
-            if (o.y != pg.op_edge[pc] || o.z < (mode == 3 && nint_nodes > 0 ? -1 : 0) || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
+            if (o.y != pg.op_edge[pc] || o.z < ((mode == 3 || mode == 1) && nint_nodes > 0 ? -1 : 0) || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
             if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
         } else if (code == OP_PUSH || code == OP_POPMUL) {
             if (o.y < 0 || o.y >= D) return "down program: stack slot out of range";

@@ -49,6 +49,9 @@ struct Up4Args {
     double *MVS;                   /* null: per-site planes in MV */
     const double *wsite;           /* [n] site weights of the chunk or null */
     const int *visits;             /* k_up4_nodes: records of plk_up_nodes_build() (plk_program.h) */
+    const double *ptab;            /* k_up4_nodes: pair tables [C][npairs][nchar * nchar][4]: the message P_a (P_b B_b o P_c B_c) of a
+                                      two-leaf node, by the combined code of its leaves (k_build_tables_pt); null = none */
+    int npairs;
     int nvisits;
 };
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(UD4_BLOCK) void k_down_fused4(Up4Args a, const int4
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
                 /* y = CSR edge, z = storage index of the child node whose vector is now final */
-                if (valid) st4(a.LN + (((size_t)oz * a.C + c) * n + slc) * 4, cur);
+                if (valid && oz >= 0) st4(a.LN + (((size_t)oz * a.C + c) * n + slc) * 4, cur);   /* oz < 0: a two-leaf node whose message the up pass takes from a pair table */
                 v4 m = mv4(Pm + ((size_t)c * a.E + oy) * 16, cur);
                 if (const4(cur)) m = cur;
                 cur = m;
@@ -633,6 +636,17 @@ __device__ __forceinline__ V at_u(const V *base, unsigned off)
     return base[off];
 }
 
+/* message of a two-leaf node b towards its parent, P_b (P_b0 B_b0 o P_b1 B_b1), as a row of its pair table: the
+ * reference forms it by two _prune_update_prob calls and one product per site (src/evaluate_site_lhood.c:36-56); the
+ * table is built once per (category, node) in double-double.  Neither pass moves L_b through HBM for such a node. */
+__device__ static inline v4 u4n_pair_message(const Up4Args &a, int c, int pair, int b, unsigned us)
+{
+    const int e0 = as_uniform(a.indptr)[b];
+    const int b0 = as_uniform(a.indices)[e0], b1 = as_uniform(a.indices)[e0 + 1];
+    const unsigned comb = (unsigned)at_u(a.codes + (size_t)b0 * a.Spad + a.s0, us) * (unsigned)a.nchar + (unsigned)at_u(a.codes + (size_t)b1 * a.Spad + a.s0, us);
+    return ld4u(a.ptab + ((size_t)c * a.npairs + pair) * a.nchar * a.nchar * 4, 4u * comb);
+}
+
 template <int CM>
 __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up4_nodes(Up4Args a)
 {
@@ -665,6 +679,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
 #define U4N_MESSAGE(J, C_, M)                                                                             \
         do { const int b_ = ch[4 * (J)], t_ = ch[4 * (J) + 1], pos_ = ch[4 * (J) + 2] >> PLK_UN_POS_SHIFT; \
              if (t_ >= 0) M = ld4u(a.tip + (size_t)(C_) * tabc + (size_t)t_ * a.nchar * 4, 4u * at_u(a.codes + (size_t)b_ * a.Spad + a.s0, us)); \
+             else if (t_ < -1) M = u4n_pair_message(a, C_, -2 - t_, b_, us);                              \
              else { const v4 x_ = ld4u(a.LN + ((size_t)ch[4 * (J) + 3] * a.C + (C_)) * n * 4, us4);        \
                     M = mv4(Pm + ((size_t)(C_) * a.E + e0 + pos_) * 16, x_);                              \
                     if (const4(x_)) M = x_; } } while (0)
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 const double sc = slot >= 0 ? at_u(a.SC + ((size_t)slot * a.C + c) * n, us) : 1.0;
                 v4 m0, m1 = one, ob = one;
                 if (ch[1] >= 0) m0 = ld4u(tipc + (size_t)ch[1] * a.nchar * 4, cd0);
+                else if (ch[1] < -1) m0 = u4n_pair_message(a, c, -2 - ch[1], ch[0], us);
                 else {
                     const v4 x = ld4u(a.LN + ((size_t)ch[3] * a.C + c) * n * 4, us4);
                     m0 = mv4(Pm + ((size_t)c * a.E + e0 + (fl0 >> PLK_UN_POS_SHIFT)) * 16, x);
@@ -690,6 +706,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 }
                 if (deg == 2) {
                     if (ch[5] >= 0) m1 = ld4u(tipc + (size_t)ch[5] * a.nchar * 4, cd1);
+                    else if (ch[5] < -1) m1 = u4n_pair_message(a, c, -2 - ch[5], ch[4], us);
                     else {
                         const v4 x = ld4u(a.LN + ((size_t)ch[7] * a.C + c) * n * 4, us4);
                         m1 = mv4(Pm + ((size_t)c * a.E + e0 + (fl1 >> PLK_UN_POS_SHIFT)) * 16, x);

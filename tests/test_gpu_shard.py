@@ -124,26 +124,39 @@ def test_three_ranks_with_an_empty_one(tmp_path):
     assert _close(got["marginal"], m, scale=float(S)) <= 1e-13
 
 
-def test_engine_rccl_reduction_world_size_one():
+_RCCL_WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import torch
+from phyly_amd import synth
+from phyly_amd.engine import Engine
+wl = synth.Workload(2)
+eng = Engine(0)
+wl.setup_engine(eng)
+eng.set_patterns_codes(wl.simulate(5000), wl.defs)
+_, (hi, lo) = eng.ll(per_site=False)
+eng.comm_init(1, 0, Engine.comm_unique_id())
+red = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+for _ in range(3):
+    eng.update_edge_rates(wl.edge_rates_csr)
+    eng.ll_async(sum_device_ptr=red.data_ptr())
+    eng.allreduce_sum_async(red.data_ptr(), 2)
+torch.cuda.synchronize()
+assert red.tolist() == [hi, lo], (red.tolist(), hi, lo)
+eng.comm_destroy()
+eng.close()
+print("RCCL_OK")
+"""
+
+
+def test_engine_rccl_reduction_world_size_one(tmp_path):
     """plk_comm_* / plk_allreduce_sum_async (include/plk.h): the engine loads the process's RCCL and queues the reduction
     on its own stream.  One rank is all the one-GPU box allows (RCCL refuses two ranks on a device): the sum over one
-    rank is the input, queued behind an ll evaluation whose {hi, lo} it reduces in place."""
-    import torch
-    from phyly_amd import synth
-    from phyly_amd.engine import Engine
-    wl = synth.Workload(2)
-    eng = Engine(0)
-    wl.setup_engine(eng)
-    eng.set_patterns_codes(wl.simulate(5000), wl.defs)
-    _, (hi, lo) = eng.ll(per_site=False)
-    eng.comm_init(1, 0, Engine.comm_unique_id())
-    red = torch.zeros(2, dtype=torch.float64, device="cuda:0")
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    for _ in range(3):
-        eng.update_edge_rates(wl.edge_rates_csr)
-        eng.ll_async(sum_device_ptr=red.data_ptr())
-        eng.allreduce_sum_async(red.data_ptr(), 2)
-    torch.cuda.synchronize()
-    assert red.tolist() == [hi, lo]
-    eng.comm_destroy()
-    eng.close()
+    rank is the input, queued behind an ll evaluation whose {hi, lo} it reduces in place.  In a fresh process, as a
+    rank of a real job is (RCCL's own initialisation does not always succeed late in a long-lived test process)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % {"root": ROOT})
+    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"RCCL_OK" in p.stdout, p.stderr.decode()[-3000:]
