@@ -267,9 +267,22 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
     int kk = k * k;
     for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
         int i = idx / k, j = idx - i * k;
-        dd acc = dd_make(0.0, 0.0);
-        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(A[i * k + l], B[l * k + j]));
-        Cm[idx] = acc;
+        /* compensated dot product (Ogita, Rump & Oishi's Dot2 on double-double operands): the high words are summed with
+         * an exact two-sum, every rounding error and the cross terms go to one low accumulator, one renormalisation at the
+         * end -- 12 flops per term instead of the 28 of dd_add(dd_mul); the result carries ~2^-104 relative to
+         * sum |a||b|, the same class as before (K1 for k = 61: 0.99 -> see profiles/r03_exp_codon_kernel_variants.json) */
+        double sh = 0.0, sl = 0.0;
+        for (int l = 0; l < k; l++) {
+            const dd a = A[i * k + l], b = B[l * k + j];
+            const double p = a.hi * b.hi;
+            double e = fma(a.hi, b.hi, -p);
+            e = fma(a.hi, b.lo, e);
+            e = fma(a.lo, b.hi, e);
+            const double t = sh + p, bb = t - sh;
+            sl += ((sh - (t - bb)) + (p - bb)) + e;
+            sh = t;
+        }
+        Cm[idx] = dd_quick_two_sum(sh, sl);
     }
 }
 
@@ -1591,7 +1604,15 @@ static bool build_fused_pt(plk_engine *h)
     case 3: cands = {{1, 512}}; break;
     case 5: cands = {{2, 1024}}; break;
     case 6: cands = {{2, 1536}}; break;
-    default: cands = {{2, 1536}, {2, 1024}, {1, 1024}, {1, 512}}; break;
+    default: {
+        /* 1536-site tiles run 1.3 x as long as 1024-site tiles (109 against 84 us a round at BASELINE config 3) and carry 1.5 x
+         * the sites; every CU runs ceil(tiles / CUs) rounds.  Few sites per GPU (a rank of an 8-way split) can need fewer
+         * round-times with the smaller tile: 1.25M sites are 4 rounds of 1536 (436 us) or 5 rounds of 1024 (420 us). */
+        auto rounds = [&](long tile) { const long nt = (h->S + tile - 1) / tile; return (double)((nt + h->num_cus - 1) / h->num_cus); };
+        if (h->S > 0 && rounds(1024) * 1.0 < rounds(1536) * 1.3) cands = {{2, 1024}, {2, 1536}, {1, 1024}, {1, 512}};
+        else cands = {{2, 1536}, {2, 1024}, {1, 1024}, {1, 512}};
+        break;
+    }
     }
     for (const Cand &cd : cands) {
         const long limit = (long)plk_pt_lds_limit(cd.tile);
