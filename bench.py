@@ -47,7 +47,7 @@ FP64_PEAK = 78.6e12        # flop/s, fp64 vector = fp64 matrix dense peak (SURVE
 # sources a kernel's measured HBM traffic depends on (profiles/traffic_*.json record their git blob hashes)
 KERNEL_SOURCES = {
     "k_ll_fused4": ["plk_fused4_asm.h", "plk_fused4_v4.h", "plk_fused4_v4_asm.h", "plk_fused4.h", "plk_program.h"],
-    "k_ll_vec": ["plk_vec.h", "plk_vec_matvec_asm.h"],
+    "k_ll_vec": ["plk_vec.h", "plk_vec_matvec_asm.h", "plk_program.h"],
     "k_ll_mfma": ["plk_mfma.h"],
     "k_ll_generic": ["plk_engine.hip"],
     "deriv4": ["plk_updown4.h", "plk_down4_asm.h"],

@@ -104,6 +104,8 @@ struct plk_engine {
     bool fmt_pt = false;                 /* the uploaded kind-1 formats are the pair-table ones */
     unsigned *d_words_pt = nullptr;
     PlkFusedV4 fv4;                      /* 64-bit ops of the two-sites-per-lane interpreter */
+    PlkVecPT vpt;                        /* the vector ll kernel's program on pair tables */
+    bool vec_pt = false;
     int pt_kind = 0, pt_tile_sites = 0;  /* 1: k_ll_fused4_asm_pt, 2: k_ll_fused4_v4; sites per tile of the uploaded formats */
     unsigned v4_tip_base = 0;            /* LDS address of the table image = static LDS of the kernel */
     int *d_row_nodes = nullptr, *d_tabs = nullptr;   /* [2][rows] staged-row nodes; [4][ntab] unit, edge, leaf edges of a pair */
@@ -1301,7 +1303,7 @@ extern "C" int plk_get_info(plk_engine *h, int what, long *out)
     case PLK_INFO_LL_KERNEL: *out = h->info_ll_kernel; return PLK_OK;
     case PLK_INFO_LL_VARIANT: *out = h->info_ll_variant; return PLK_OK;
     case PLK_INFO_LL_EXEC_FLOPS: *out = h->info_ll_exec_flops; return PLK_OK;
-    case PLK_INFO_PAIR_TABLES: *out = h->fmt_pt && h->fmt_kind == 1 && !h->fmt_dirty ? h->fpt.npairs : 0; return PLK_OK;
+    case PLK_INFO_PAIR_TABLES: *out = !h->fmt_dirty && ((h->fmt_pt && h->fmt_kind == 1) || (h->vec_pt && h->fmt_kind == 4)) ? h->fpt.npairs : 0; return PLK_OK;
     case PLK_INFO_STACK_SLOTS: *out = h->slots_needed; return PLK_OK;
     case PLK_INFO_PROGRAM_OPS: *out = (long)h->ops.size(); return PLK_OK;
     case PLK_INFO_LAST_LL_KERNEL_NS: *out = h->info_ll_kernel_ns; return PLK_OK;
@@ -1717,7 +1719,35 @@ static int upload_formats(plk_engine *h, long kind)
         if ((rc = dev_upload(h, &h->d_ops, reinterpret_cast<const int2 *>(gops.data()), gops.size()))) return rc;
         if ((rc = dev_upload(h, &h->d_op_edge, h->op_edge.data(), h->op_edge.size()))) return rc;
         if ((rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * std::max(nops, 1) * h->K * h->K))) return rc;
-        if (kind == 4) {
+        h->vec_pt = false;
+        if (kind == 4 && h->opt_pair_tables && h->K <= 32 && !h->obs_nodes.empty()) {
+            /* pair-table program for the vector kernel: two-leaf subtrees as rows of L2-resident tables (nchar^2 rows of K
+             * doubles each), as many as 64 MB of tables per category take */
+            const long per_pair = (long)h->nchar * h->nchar * h->K * (long)sizeof(double);
+            const int max_pairs = (int)std::min<long>(INT_MAX, (64L << 20) / std::max<long>(per_pair, 1));
+            plk_fused_pt_build(h->N, h->indptr.data(), h->indices.data(), h->pg, h->nchar, max_pairs, h->fpt, false);
+            if (h->fpt.npairs > 0) {
+                plk_vec_pt_build(h->fpt, h->nchar, h->vpt);
+                const std::string bad = plk_vec_pt_check(h->N, h->indptr.data(), h->indices.data(), h->pg, h->fpt, h->vpt, h->nchar, h->E);
+                if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
+                const PlkFusedPT &f = h->fpt;
+                std::vector<int> rn(f.row_node);
+                rn.insert(rn.end(), f.row_node2.begin(), f.row_node2.end());
+                std::vector<int> tabs(f.tab_unit);
+                tabs.insert(tabs.end(), f.tab_edge.begin(), f.tab_edge.end());
+                tabs.insert(tabs.end(), f.tab_eb.begin(), f.tab_eb.end());
+                tabs.insert(tabs.end(), f.tab_ec.begin(), f.tab_ec.end());
+                if ((rc = dev_upload(h, &h->d_row_nodes, rn.data(), rn.size())) || (rc = dev_upload(h, &h->d_tabs, tabs.data(), tabs.size())) ||
+                    (rc = dev_upload(h, &h->d_mops, reinterpret_cast<const int4 *>(h->vpt.ops.data()), h->vpt.ops.size())) ||
+                    (rc = dev_upload(h, &h->d_op_edge, h->vpt.op_edge.data(), h->vpt.op_edge.size())) ||
+                    (rc = dev_reserve(h, &h->d_PS, &h->ps_cap, (size_t)h->C * h->vpt.ops.size() * h->K * h->K)) ||
+                    (rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * f.units * h->nchar * h->K))) return rc;
+                h->vec_pt = true;
+            }
+        }
+        if (kind == 4 && h->vec_pt) {
+            /* formats uploaded above */
+        } else if (kind == 4) {
             if ((rc = dev_reserve(h, &h->d_tip, &h->tip_cap, (size_t)h->C * (ntips + 1) * h->nchar * h->K))) return rc;
             /* vector program: observation ops chained two ahead (value of the next op, code of the one after) */
             PlkChain ch;
@@ -1759,6 +1789,16 @@ static int build_tables(plk_engine *h, long kind)
         /* the fused formats are written by K1 itself (ExpmPost) */
         return run_expm(h, true);
     } else {
+        if (kind == 4 && h->vec_pt) {
+            const int nv = (int)h->vpt.ops.size(), ntab = (int)h->fpt.tab_unit.size();
+            hipLaunchKernelGGL(k_build_stream, dim3(nv, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
+                               h->k, K, h->E, nv, h->d_op_edge, h->d_P, h->d_PS);
+            hipLaunchKernelGGL(k_build_tables_pt_vec, dim3(ntab, C, 8), dim3(256), (size_t)4 * h->nchar * h->k * sizeof(double), h->stream,
+                               h->k, K, h->E, ntab, h->fpt.units, h->nchar, h->d_tabs, h->d_Pdd, h->d_defs, h->d_tip);
+            HIPCHK(h, hipGetLastError());
+            h->tables_dirty = false;
+            return PLK_OK;
+        }
         if (nops > 0)
             hipLaunchKernelGGL(k_build_stream, dim3(nops, C), dim3(K * K >= 256 ? 256 : 64), 0, h->stream,
                                h->k, K, h->E, nops, h->d_op_edge, h->d_P, h->d_PS);
@@ -1921,6 +1961,12 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.S = S; a.Spad = h->Spad; a.k = h->k; a.C = h->C; a.nops = nops; a.ntips = ntips; a.nchar = h->nchar;
         a.root_mode = h->root_mode; a.ops = h->d_mops; a.PS = h->d_PS; a.tip = h->d_tip; a.codes = h->d_codes;
         a.obs_nodes = h->d_obs_nodes; a.first_slot = h->mfma_first_slot; a.first_row = h->mfma_first_row; a.second_row = h->vec_second_row;
+        a.obs_nodes2 = nullptr; a.units = 0;
+        if (h->vec_pt) {
+            const int nrows = (int)h->fpt.row_node.size();
+            a.nops = (int)h->vpt.ops.size(); a.obs_nodes = h->d_row_nodes; a.obs_nodes2 = h->d_row_nodes + nrows; a.units = h->fpt.units;
+            a.first_slot = 0; a.first_row = h->vpt.first_row;
+        }
         a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w; a.w = h->d_w; a.slots = h->d_slots; a.site_ll = d_out;
         a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
         /* register stack (PLK_OPT_VEC_REG_STACK, default on): the window of three slots that takes most pushes */
@@ -1981,7 +2027,9 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
     {
         /* executed fp64 work per site (PLK_INFO_LL_EXEC_FLOPS): products and elementwise multiplies of the program that ran */
         long nprod = 0, nmul = 0;
-        if (fused && h->fmt_pt) {
+        if (vec && h->vec_pt) {
+            for (const PlkFusedPT::VOp &o : h->fpt.vops) { if (o.code == OP_MATVEC) nprod++; if (o.code == OP_TIP_MUL || o.code == OP_POPMUL) nmul++; }
+        } else if (fused && h->fmt_pt) {
             nprod = (long)h->fpt.mat_edge.size();
             for (unsigned w : h->fpt.words) {
                 const unsigned hx = w & 31;

@@ -438,6 +438,9 @@ struct PlkFusedPT {
     std::vector<int> tab_unit, tab_edge, tab_eb, tab_ec;   /* first unit | leaf edge, edge above the cherry or -1 | pair: leaf edges, else -1 */
     int units = 0, npairs = 0;
     int first_unit = 0, first_row = 0, second_row = 0;
+    /* the program after folding the cherries, op by op (what the words encode; the vector kernel's int4 program is made from it) */
+    struct VOp { int code, unit, row, d, edge; };
+    std::vector<VOp> vops;
 };
 
 /* the node whose CSR child range holds edge idx */
@@ -465,8 +468,9 @@ static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const
                                       bool fuse_set = false)
 {
     const int nops = (int)pg.ops.size();
-    struct VOp { int code, unit, row, d; };
-    std::vector<VOp> v;
+    typedef PlkFusedPT::VOp VOp;
+    std::vector<VOp> &v = fu.vops;
+    v.clear();
     fu.mat_edge.clear(); fu.row_node.clear(); fu.row_node2.clear();
     fu.tab_unit.clear(); fu.tab_edge.clear(); fu.tab_eb.clear(); fu.tab_ec.clear();
     fu.units = 0; fu.npairs = 0;
@@ -485,19 +489,19 @@ static inline void plk_fused_pt_build(int N, const int *ip, const int *ix, const
         if (code == OP_TIP_SET && fu.npairs < max_pairs && plk_pair_at(N, ip, ix, pg, (size_t)pc)) {
             const int row = (int)fu.row_node.size();
             fu.row_node.push_back(pg.ops[pc].y); fu.row_node2.push_back(pg.ops[pc + 1].y);
-            v.push_back(VOp{OP_TIP_SET, table(pg.op_edge[pc + 2], pg.op_edge[pc], pg.op_edge[pc + 1], nchar), row, 0});
+            v.push_back(VOp{OP_TIP_SET, table(pg.op_edge[pc + 2], pg.op_edge[pc], pg.op_edge[pc + 1], nchar), row, 0, -1});
             fu.npairs++;
             pc += 2;
         } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
-            v.push_back(VOp{code, table(pg.op_edge[pc], -1, -1, 1), single_row(pg.ops[pc].y), 0});
+            v.push_back(VOp{code, table(pg.op_edge[pc], -1, -1, 1), single_row(pg.ops[pc].y), 0, -1});
         } else if (code == OP_NODE_MUL) {
             if (pseudo_unit < 0) pseudo_unit = table(-1, -1, -1, 1);
-            v.push_back(VOp{OP_TIP_MUL, pseudo_unit, single_row(pg.ops[pc].y), 0});
+            v.push_back(VOp{OP_TIP_MUL, pseudo_unit, single_row(pg.ops[pc].y), 0, -1});
         } else if (code == OP_MATVEC) {
             fu.mat_edge.push_back(pg.op_edge[pc]);
-            v.push_back(VOp{OP_MATVEC, 0, 0, 0});
+            v.push_back(VOp{OP_MATVEC, 0, 0, 0, pg.op_edge[pc]});
         } else {
-            v.push_back(VOp{code, 0, 0, pg.ops[pc].y});
+            v.push_back(VOp{code, 0, 0, pg.ops[pc].y, -1});
         }
     }
     if (pseudo_unit < 0) table(-1, -1, -1, 1);      /* always present: keeps the image non-empty and the layout regular */
@@ -733,6 +737,105 @@ static inline std::string plk_fused_check_v4(const PlkFusedPT &fu, const PlkFuse
         if (!plk_word_is_obs(hidx)) { if (hi != 0) return plk_fmt("v4 program: stray fields in op %ld", (long)i); continue; }
         if (!y_ok(hi >> 16, (w >> 5) & 0x7ff) || !z_ok(hi & 0xffff, w >> 16)) return plk_fmt("v4 program: fields of op %ld", (long)i);
     }
+    return "";
+}
+
+/*
+ * The vector ll kernel (k_ll_vec, plk_vec.h) on the pair-table program: int4 ops
+ *   observation (TIP_SET / TIP_MUL)  x = opcode, y = first row of the op's table (unit * nchar: the kernel adds the code),
+ *                                    w = staged row of the NEXT observation op (cyclic)
+ *   MATVEC                           x = opcode, z = op index of the next MATVEC (cyclic; its matrix lines are touched ahead)
+ *   PUSH / POPMUL y = slot;  SCALE
+ * op_edge[pc] = CSR edge of a MATVEC op (-1 otherwise): the matrix stream is indexed by op.
+ */
+struct PlkVecPT {
+    std::vector<plk_op4> ops;
+    std::vector<int> op_edge;
+    int first_base = 0, first_row = 0;
+};
+
+static inline void plk_vec_pt_build(const PlkFusedPT &fu, int nchar, PlkVecPT &vp)
+{
+    const int n = (int)fu.vops.size();
+    vp.ops.assign(n, plk_op4{OP_END, 0, 0, 0});
+    vp.op_edge.assign(n, -1);
+    std::vector<int> obs_idx, mv_idx;
+    for (int i = 0; i < n; i++) {
+        const PlkFusedPT::VOp &o = fu.vops[i];
+        vp.ops[i].x = o.code;
+        if (o.code == OP_TIP_SET || o.code == OP_TIP_MUL) { vp.ops[i].y = o.unit * nchar; obs_idx.push_back(i); }
+        else if (o.code == OP_MATVEC) { vp.op_edge[i] = o.edge; mv_idx.push_back(i); }
+        else if (o.code == OP_PUSH || o.code == OP_POPMUL) vp.ops[i].y = o.d;
+    }
+    for (size_t q = 0; q < obs_idx.size(); q++) vp.ops[obs_idx[q]].w = fu.vops[obs_idx[(q + 1) % obs_idx.size()]].row;
+    for (size_t q = 0; q < mv_idx.size(); q++) vp.ops[mv_idx[q]].z = mv_idx[(q + 1) % mv_idx.size()];
+    vp.first_base = obs_idx.empty() ? 0 : fu.vops[obs_idx[0]].unit * nchar;
+    vp.first_row = obs_idx.empty() ? 0 : fu.vops[obs_idx[0]].row;
+}
+
+/* replay against the program: the ops fold exactly the program's ops (a pair look-up stands for a cherry's three ops), rows
+ * and tables are the ones of the op, every index is in range */
+static inline std::string plk_vec_pt_check(int N, const int *ip, const int *ix, const PlkProgram &pg, const PlkFusedPT &fu, const PlkVecPT &vp,
+                                           int nchar, int E)
+{
+    const int nops = (int)pg.ops.size(), n = (int)vp.ops.size(), nrows = (int)fu.row_node.size(), ntab = (int)fu.tab_unit.size();
+    if ((int)vp.op_edge.size() != n || (int)fu.vops.size() != n) return "vec pt program: sizes";
+    std::vector<int> table_at(std::max(fu.units, 1), -1);
+    for (int t = 0; t < ntab; t++) if (fu.tab_unit[t] >= 0 && fu.tab_unit[t] < fu.units) table_at[fu.tab_unit[t]] = t;
+    size_t pc = 0;
+    long next_row = vp.first_row, next_base = vp.first_base;
+    bool first = true;
+    std::vector<char> full(std::max(pg.slots_needed, 1), 0);
+    int last_mv = -1, first_mv = -1;
+    for (int i = 0; i < n; i++) {
+        const plk_op4 &o = vp.ops[i];
+        const int code = o.x & 0xff;
+        if (pc >= (size_t)nops) return "vec pt program: more ops than the program";
+        const int pcode = pg.ops[pc].x & 0xff;
+        if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+            if (o.y % nchar != 0 || o.y / nchar < 0 || o.y / nchar >= fu.units || table_at[o.y / nchar] < 0) return plk_fmt("vec pt program: op %ld names no table", i);
+            const int t = table_at[o.y / nchar];
+            if (o.w < 0 || o.w >= nrows) return plk_fmt("vec pt program: op %ld prefetches a row out of range", i);
+            if (next_row < 0 || next_row >= nrows || (!first && false)) return "vec pt program: row chain";
+            if (next_base != o.y) return plk_fmt("vec pt program: op %ld: the chain's table is not the op's", i);
+            const int row = (int)next_row;
+            if (fu.tab_eb[t] >= 0) {
+                if (code != OP_TIP_SET || !plk_pair_at(N, ip, ix, pg, pc)) return plk_fmt("vec pt program: op %ld is a pair look-up where the program has no cherry", i);
+                if (fu.tab_eb[t] != pg.op_edge[pc] || fu.tab_ec[t] != pg.op_edge[pc + 1] || fu.tab_edge[t] != pg.op_edge[pc + 2]) return plk_fmt("vec pt program: pair table of op %ld", i);
+                if (fu.row_node[row] != pg.ops[pc].y || fu.row_node2[row] != pg.ops[pc + 1].y) return plk_fmt("vec pt program: pair row of op %ld", i);
+                pc += 3;
+            } else {
+                if (pcode != OP_TIP_SET && pcode != OP_TIP_MUL && pcode != OP_NODE_MUL) return plk_fmt("vec pt program: op %ld is not an observation", i);
+                if ((code == OP_TIP_SET) != (pcode == OP_TIP_SET)) return plk_fmt("vec pt program: op %ld SET/MUL", i);
+                if (fu.row_node[row] != pg.ops[pc].y || fu.row_node2[row] != -1) return plk_fmt("vec pt program: row of op %ld", i);
+                if (fu.tab_edge[t] != (pcode == OP_NODE_MUL ? -1 : pg.op_edge[pc])) return plk_fmt("vec pt program: table of op %ld", i);
+                pc++;
+            }
+            /* the chain: this op names the row of the next observation; its table base is found at that op */
+            next_row = o.w;
+            next_base = -1;
+            for (int q = 1; q <= n; q++) {
+                const plk_op4 &o2 = vp.ops[(i + q) % n];
+                if ((o2.x & 0xff) == OP_TIP_SET || (o2.x & 0xff) == OP_TIP_MUL) { next_base = o2.y; break; }
+            }
+            first = false;
+        } else if (code == OP_MATVEC) {
+            if (pcode != OP_MATVEC || vp.op_edge[i] != pg.op_edge[pc] || vp.op_edge[i] < 0 || vp.op_edge[i] >= E) return plk_fmt("vec pt program: product %ld", i);
+            if (o.z < 0 || o.z >= n || (vp.ops[o.z].x & 0xff) != OP_MATVEC) return plk_fmt("vec pt program: op %ld names no next product", i);
+            if (first_mv < 0) first_mv = i;
+            last_mv = i;
+            pc++;
+        } else if (code == OP_PUSH || code == OP_POPMUL) {
+            if (pcode != code || o.y != pg.ops[pc].y || o.y < 0 || o.y >= (int)full.size() || (full[o.y] != 0) == (code == OP_PUSH)) return plk_fmt("vec pt program: stack op %ld", i);
+            full[o.y] = code == OP_PUSH;
+            pc++;
+        } else if (code == OP_SCALE) {
+            if (pcode != OP_SCALE) return plk_fmt("vec pt program: op %ld", i);
+            pc++;
+        } else return plk_fmt("vec pt program: unknown op %ld", i);
+    }
+    if ((int)pc != nops) return "vec pt program: the program's ops are not all covered";
+    if (last_mv >= 0 && vp.ops[last_mv].z != first_mv) return "vec pt program: the product chain does not wrap to the first";
     return "";
 }
 

@@ -31,6 +31,12 @@ struct VecArgs {
     const double *cat_prior, *root_w, *w;
     double *slots;            /* [nslots][K][S] */
     int reg_lo;               /* NREG > 0: stack slots reg_lo .. reg_lo + NREG - 1 live in registers, the others in `slots` */
+    /* pair-table program (round 3; plk_vec_pt_build of plk_program.h): obs_nodes2 != null.  An observation op's y is then the
+     * first row of its table (tip = [C][units * nchar][K]), a staged row may name two nodes (a two-leaf subtree: its code is
+     * code(b) * nchar + code(c), its table holds P_a (P_b def_i o P_c def_j)), and the matrix stream has no entry for the
+     * edges folded into tables */
+    const int *obs_nodes2;
+    int units;
     double *site_ll;
     dd *partial;
 };
@@ -101,7 +107,7 @@ __device__ __forceinline__ void k_ll_vec_body(const VecArgs &a)
     const long sc = valid ? s : a.S - 1;
     const PLK_AS4 int *ops = as_uniform(reinterpret_cast<const int *>(a.ops));
     const PLK_AS4 double *prior = as_uniform(a.cat_prior), *rw = as_uniform(a.root_w);
-    const size_t tabc = (size_t)(a.ntips + 1) * a.nchar * K;
+    const size_t tabc = (a.obs_nodes2 ? (size_t)a.units : (size_t)(a.ntips + 1)) * a.nchar * K;
 
     double sum = 0.0;
     int Eexp = 0;
@@ -111,7 +117,15 @@ __device__ __forceinline__ void k_ll_vec_body(const VecArgs &a)
      * register pairs) is what k_down_vec uses, but here it cost a wave of occupancy (117 against 99 VGPRs) and 9 % of
      * the speed (6.77 against 6.2 ms at BASELINE config 4). */
     const PLK_AS4 int *obs = as_uniform(a.obs_nodes);
-    int code_next = a.first_slot >= 0 ? a.codes[(size_t)obs[a.first_row] * a.Spad + sc] : 0;
+    const PLK_AS4 int *obs2 = as_uniform(a.obs_nodes2);
+    const bool pt = a.obs_nodes2 != nullptr;
+    /* pattern code of a staged row: one node's code, or the combined code of a two-leaf subtree */
+    auto row_code = [&](int row) -> int {
+        int cd = a.codes[(size_t)obs[row] * a.Spad + sc];
+        if (pt) { const int n2 = obs2[row]; if (n2 >= 0) cd = cd * a.nchar + a.codes[(size_t)n2 * a.Spad + sc]; }
+        return cd;
+    };
+    int code_next = a.first_slot >= 0 ? row_code(a.first_row) : 0;
     for (int c = 0; c < a.C; c++) {
         double cur[K];
 #pragma unroll
@@ -136,7 +150,8 @@ __device__ __forceinline__ void k_ll_vec_body(const VecArgs &a)
             } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
                 const int ow = ops[4 * pc + 3];                     /* staged row of the next observation op (cyclic) */
                 const int t = code == OP_NODE_MUL ? a.ntips : (ox >> 8);
-                const double2 *tp = reinterpret_cast<const double2 *>(tipc + ((size_t)t * a.nchar + code_next) * K);
+                const size_t trow = pt ? (size_t)oy + code_next : (size_t)t * a.nchar + code_next;
+                const double2 *tp = reinterpret_cast<const double2 *>(tipc + trow * K);
                 if (code == OP_TIP_SET) {
 #pragma unroll
                     for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] = v.x; cur[i + 1] = v.y; }
@@ -144,7 +159,7 @@ __device__ __forceinline__ void k_ll_vec_body(const VecArgs &a)
 #pragma unroll
                     for (int i = 0; i < K; i += 2) { const double2 v = tp[i >> 1]; cur[i] *= v.x; cur[i + 1] *= v.y; }
                 }
-                code_next = a.codes[(size_t)obs[ow] * a.Spad + sc];
+                code_next = row_code(ow);
             } else if (NREG > 0 && code == OP_PUSH && oy - a.reg_lo >= 0 && oy - a.reg_lo < NREG) {
                 const int r = oy - a.reg_lo;
                 if (r == 0) vec_acc_push<0, K>(cur, std::make_integer_sequence<int, K>());
@@ -212,6 +227,72 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_ll_vec(VecArgs a) { k_ll_vec_body
 /* the register-stack variant: 2 waves per SIMD (256 registers per lane) */
 template <int K, int NREG>
 __global__ __launch_bounds__(VEC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ll_vec_rs(VecArgs a) { k_ll_vec_body<K, NREG>(a); }
+
+/* Tables of the pair-table program for K-state vectors (the k = 4 version is k_build_tables_pt in plk_engine.hip):
+ * tab[4][ntab] = first unit | edge | pair: the two leaf edges, else -1.  One block per (table, category).
+ *   single  out[code][i]         = (P_e defs[code])_i          pair  out[cb*nchar+cc][i] = (P_a (P_b defs[cb] o P_c defs[cc]))_i
+ *   pseudo  out[code][i]         = defs[code][i]
+ * in double-double from the unrounded P; a constant vector maps to itself exactly (src/util.c:276-283). */
+__global__ __launch_bounds__(256) void k_build_tables_pt_vec(int k, int K, int E, int ntab, int units, int nchar, const int *__restrict__ tab,
+                                                              const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][K] */,
+                                                              double *__restrict__ tip)
+{
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int unit = tab[t], e = tab[ntab + t], eb = tab[2 * ntab + t], ec = tab[3 * ntab + t];
+    double *out = tip + ((size_t)c * units + unit) * nchar * K;
+    const size_t kk = (size_t)k * k;
+    auto is_const = [&](const double *d) { bool cst = true; for (int j = 1; j < k; j++) cst = cst && d[j] == d[0]; return cst; };
+    /* (P_edge d)_i in double-double; d constant: d_0 */
+    auto leaf = [&](int edge, const double *d, int i) -> dd {
+        if (is_const(d)) return dd_make(d[0], 0.0);
+        const dd *Pm = Pdd + ((size_t)c * E + edge) * kk + (size_t)i * k;
+        dd acc = dd_make(0.0, 0.0);
+        for (int j = 0; j < k; j++) acc = dd_add(acc, dd_mul_d(Pm[j], d[j]));
+        return acc;
+    };
+    if (eb < 0) {
+        if (blockIdx.z != 0) return;                 /* the slices of gridDim.z are for the pair tables */
+        for (int idx = threadIdx.x; idx < nchar * K; idx += blockDim.x) {
+            const int code = idx / K, i = idx - code * K;
+            const double *d = defs + (size_t)code * K;
+            out[idx] = i >= k ? 0.0 : (e < 0 ? d[i] : leaf(e, d, i).hi);
+        }
+        return;
+    }
+    /* a pair.  Phase 1: the 2 x nchar leaf vectors P_b def[cb], P_c def[cc] (double-double) into LDS; phase 2: for this
+     * block's slice of the nchar^2 code pairs (gridDim.z slices) v = vb o vc and P_a v, one output entry per lane and step */
+    extern __shared__ double pt_lds[];                       /* [2][nchar][k] hi, then the same lo */
+    double *lh = pt_lds, *ll_ = pt_lds + (size_t)2 * nchar * k;
+    for (int idx = threadIdx.x; idx < 2 * nchar * k; idx += blockDim.x) {
+        const int which = idx / (nchar * k), rem = idx - which * nchar * k, code = rem / k, i = rem - code * k;
+        const dd v = leaf(which ? ec : eb, defs + (size_t)code * K, i);
+        lh[idx] = v.hi; ll_[idx] = v.lo;
+    }
+    __syncthreads();
+    const int ncomb = nchar * nchar, per = (ncomb + gridDim.z - 1) / gridDim.z;
+    const int c0 = blockIdx.z * per, c1 = c0 + per < ncomb ? c0 + per : ncomb;
+    const dd *Pa = Pdd + ((size_t)c * E + e) * kk;
+    for (int idx = c0 * K + threadIdx.x; idx < c1 * K; idx += blockDim.x) {
+        const int comb = idx / K, i = idx - comb * K;
+        const int cb = comb / nchar, cc = comb - cb * nchar;
+        const double *bh = lh + (size_t)cb * k, *bl = ll_ + (size_t)cb * k;
+        const double *ch = lh + (size_t)(nchar + cc) * k, *cl = ll_ + (size_t)(nchar + cc) * k;
+        double o = 0.0;
+        if (i < k) {
+            /* is the product vector constant?  (both leaves missing: it maps to itself) */
+            const dd p0 = dd_mul(dd_make(bh[0], bl[0]), dd_make(ch[0], cl[0]));
+            bool cst = true;
+            dd acc = dd_make(0.0, 0.0);
+            for (int j = 0; j < k; j++) {
+                const dd pj = dd_mul(dd_make(bh[j], bl[j]), dd_make(ch[j], cl[j]));
+                cst = cst && pj.hi == p0.hi && pj.lo == p0.lo;
+                acc = dd_add(acc, dd_mul(Pa[(size_t)i * k + j], pj));
+            }
+            o = cst ? p0.hi : acc.hi;
+        }
+        out[idx] = o;
+    }
+}
 
 /* tip[((c*(ntips+1) + t)*nchar + code)*K + i] = (P_e defs[code])[i] in double-double (exact for constant
  * definition rows, src/util.c:276-283); slot ntips (edge -1) holds defs[code] itself; entries i >= k are 0

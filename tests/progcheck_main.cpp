@@ -169,6 +169,27 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
             if (plk_fused_check_asm(N, pg, f2, nchar, D, pack4, lds).empty()) return "negative control: missing END accepted";
         }
     }
+    /* the vector ll kernel's program on pair tables (any stack depth, any nchar): every cherry, a budget of two */
+    if (!pg.obs_nodes.empty()) {
+        const int vbud[2] = {1 << 30, 2};
+        for (int bi = 0; bi < 2; bi++) {
+            PlkFusedPT fp;
+            plk_fused_pt_build(N, t.ip.data(), t.ix.data(), pg, nchar, vbud[bi], fp, false);
+            PlkVecPT vp;
+            plk_vec_pt_build(fp, nchar, vp);
+            bad = plk_vec_pt_check(N, t.ip.data(), t.ix.data(), pg, fp, vp, nchar, E);
+            if (!bad.empty()) return "vec pt budget " + std::to_string(bi) + ": " + bad;
+            if (bi == 0 && fp.npairs > 0) {           /* negative controls */
+                PlkVecPT v2 = vp;
+                for (size_t q = 0; q < v2.ops.size(); q++) if ((v2.ops[q].x & 0xff) == OP_TIP_SET) { v2.ops[q].y += nchar; break; }
+                if (plk_vec_pt_check(N, t.ip.data(), t.ix.data(), pg, fp, v2, nchar, E).empty()) return "negative control (vec pt): shifted table accepted";
+                v2 = vp;
+                bool changed = false;
+                for (size_t q = 0; q < v2.op_edge.size() && !changed; q++) if (v2.op_edge[q] >= 0) { v2.op_edge[q] = (v2.op_edge[q] + 1) % (E > 0 ? E : 1); changed = true; }
+                if (changed && E > 1 && plk_vec_pt_check(N, t.ip.data(), t.ix.data(), pg, fp, v2, nchar, E).empty()) return "negative control (vec pt): wrong matrix accepted";
+            }
+        }
+    }
     /* pair-table interpreter (k_ll_fused4_asm_pt): with every cherry as a table, with a budget of one, with none */
     if (pg.slots_needed <= 4 && nchar <= 16 && !pg.obs_nodes.empty()) {
         const int budgets[3] = {1 << 30, 1, 0};

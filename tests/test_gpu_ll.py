@@ -153,3 +153,37 @@ def test_fused_assembly_variants(eng, oracle, ns):
         assert rel_err(got, want) <= TOL
     finally:
         eng.set_option(E.OPT_FUSED_NS, 0)
+
+
+@pytest.mark.parametrize("T,k,S", [(40, 20, 700), (23, 12, 300)])
+def test_vector_kernel_pair_tables_equal_the_plain_program(oracle, T, k, S):
+    """k_ll_vec on the pair-table program (two-leaf subtrees as rows of L2-resident tables built in double-double,
+    PLK_OPT_PAIR_TABLES on, the default) against the same kernel on the plain program and against the oracle, with
+    missing data and ambiguity at the leaves."""
+    from phyly_amd import engine as E, synth
+    model = "aa20" if k == 20 else None
+    wl = synth.Workload(T=T, k=k, tree="yule", model=model, seed=31) if model else None
+    if wl is None:
+        wl = synth.Workload(T=T, k=20, tree="yule", model="aa20", seed=32)
+        # a 12-state model: the top-left block of the 20-state one
+        wl.k = k
+        wl.Q = [row[:k] for row in wl.Q[:k]]
+        wl.defs = np.vstack([np.eye(k), np.ones((1, k))])
+        wl.nchar = k + 1
+        wl.k0 = None
+        wl._cum = None
+    eng = E.Engine(0)
+    wl.setup_engine(eng)
+    codes = wl.random_codes(S, seed=5, missing_frac=0.1)
+    out = {}
+    for opt in (1, 0):
+        eng.set_option(E.OPT_PAIR_TABLES, opt)
+        eng.set_patterns_codes(codes, wl.defs)
+        ll, s = eng.ll()
+        assert eng.info(E.INFO_LL_KERNEL) == 4
+        assert (eng.info(E.INFO_PAIR_TABLES) > 0) == (opt == 1)
+        out[opt] = ll
+    eng.close()
+    want = oracle_site_ll(oracle, wl, codes)
+    for opt in (1, 0):
+        assert np.max(np.abs(out[opt] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12, opt
