@@ -249,7 +249,10 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
                                sites; 2 / 3: one site per lane (k_ll_fused4_asm_pt) on 1024 / 512 sites; 0: the round-2
                                interpreter over 256-site tiles, no pair tables */,
        PLK_OPT_VEC_REG_STACK = 7 /* 1 (default): the vector kernels (9 <= k <= 20) keep the three busiest stack slots in
-                               registers (2 waves per SIMD); 0: every waiting vector goes through HBM slots (round 2) */ };
+                               registers (2 waves per SIMD); 0: every waiting vector goes through HBM slots (round 2) */,
+       PLK_OPT_MFMA_NS2 = 8 /* 1: the matrix-core ll kernel for 33 <= k <= 64 gives a wave two groups of 16 sites (every staged
+                               matrix and every fragment read serve 128 sites of a workgroup); 0 (default): one group.  Measured
+                               equal at BASELINE config 5 */ };
 
 /* ------------------------------------------------------------------------------------------------------------
  * Several GPUs in one process: a group of engines, one per listed device, behind the same calls.

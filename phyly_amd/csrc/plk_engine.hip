@@ -139,7 +139,7 @@ struct plk_engine {
     double *d_work = nullptr; size_t work_cap = 0;   /* deriv / marginal workspace */
 
     /* options / info */
-    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1, opt_vec_reg_stack = 1;
+    long opt_force_generic = 0, opt_site_chunk = 0, opt_fused_ns = 0, opt_fused_asm = 1, opt_mfma = 1, opt_up_nodes = 2, opt_pair_tables = 1, opt_vec_reg_stack = 1, opt_mfma_ns2 = 0;
     void *comm = nullptr;                /* ncclComm_t of the one-process-per-GPU reduction step */
     int comm_ranks = 0;
     long info_ll_kernel = 0, info_ll_kernel_ns = 0, info_ll_total_ns = 0, info_ll_variant = 0, info_ll_exec_flops = 0;
@@ -1262,6 +1262,7 @@ extern "C" int plk_set_option(plk_engine *h, int option, long value)
     if (option == PLK_OPT_FUSED_ASM) { h->opt_fused_asm = value; h->fmt_dirty = true; return PLK_OK; }
     if (option == PLK_OPT_UP_NODES) { h->opt_up_nodes = value; return PLK_OK; }
     if (option == PLK_OPT_MFMA) { h->opt_mfma = value; return PLK_OK; }
+    if (option == PLK_OPT_MFMA_NS2) { h->opt_mfma_ns2 = value; return PLK_OK; }
     if (option == PLK_OPT_VEC_REG_STACK) { h->opt_vec_reg_stack = value; return PLK_OK; }
     if (option == PLK_OPT_PAIR_TABLES) { h->opt_pair_tables = value; h->fmt_dirty = true; return PLK_OK; }
     h->err = "plk_set_option: unknown option";
@@ -1982,9 +1983,12 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         /* 9 <= k <= 64 with compact codes: fp64 matrix-core kernel (plk_mfma.h) */
         const int T = (h->k + 15) / 16, R = 4 * T, kk4 = (h->k + 3) / 4;
         const int nops = (int)h->ops.size(), ntips = (int)h->tip_edge.size();
-        grid = (unsigned)((S + MF_SITES - 1) / MF_SITES);
+        /* two 16-site groups per wave (PLK_OPT_MFMA_NS2, default on) when the staged code rows of 128 sites fit the LDS */
+        const bool ns2 = h->opt_mfma_ns2 == 1 && T >= 3 && (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)(2 * MF_SITES) <= PLK_LDS_LIMIT;
+        const int wg_sites = ns2 ? 2 * MF_SITES : MF_SITES;
+        grid = (unsigned)((S + wg_sites - 1) / wg_sites);
         if (want_sum) { if ((rc = dev_reserve(h, &h->d_partial, &h->partial_cap, (size_t)grid + PLK_PARTIAL_OFF))) return rc; }
-        const long slot_stride = (long)grid * MF_SITES * 4;
+        const long slot_stride = (long)grid * wg_sites * 4;
         const int nslots = std::max(h->slots_needed, 1);
         if ((rc = dev_reserve(h, &h->d_slots, &h->slots_cap, (size_t)nslots * R * slot_stride))) return rc;
         MfmaArgs a;
@@ -1995,8 +1999,11 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
         a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_wd = h->d_root_wd; a.w = h->d_w;
         a.slots = h->d_slots; a.slot_stride = slot_stride; a.site_ll = d_out;
         a.partial = want_sum ? h->d_partial + PLK_PARTIAL_OFF : nullptr;
-        const size_t lds = mfma_ll_lds_bytes(h);
-        if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        const size_t lds = ns2 ? (size_t)T * kk4 * 64 * sizeof(double) + h->obs_nodes.size() * (size_t)(2 * MF_SITES) : mfma_ll_lds_bytes(h);
+        if (false) {}
+        else if (ns2 && T == 3) hipLaunchKernelGGL(k_ll_mfma_ns2<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else if (ns2) hipLaunchKernelGGL(k_ll_mfma_ns2<4>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
+        else if (T == 1) hipLaunchKernelGGL(k_ll_mfma<1>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 2) hipLaunchKernelGGL(k_ll_mfma<2>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else if (T == 3) hipLaunchKernelGGL(k_ll_mfma_occ4<3>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);
         else hipLaunchKernelGGL(k_ll_mfma_occ4<4>, dim3(grid), dim3(MF_BLOCK), lds, h->stream, a);

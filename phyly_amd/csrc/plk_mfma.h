@@ -52,18 +52,18 @@ struct MfmaArgs {
 /* pattern codes of the block's 64 sites for every observed node: 16 dwords per row; eight (node lookup, code dword)
  * pairs per lane are in flight at a time instead of one */
 __device__ static inline void mf_stage_codes(uint8_t *code_lds, const uint8_t *codes, const int *obs_nodes, int nobs, long Spad,
-                                             size_t site0, int tid)
+                                             size_t site0, int tid, int sites = MF_SITES)
 {
     uint32_t *dst = reinterpret_cast<uint32_t *>(code_lds);
-    const int ndw = nobs * (MF_SITES / 4);
+    const int ndw = nobs * (sites / 4);
     for (int i0 = tid; i0 < ndw; i0 += 8 * MF_BLOCK) {
         int node[8];
         uint32_t q[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int idx = i0 + u * MF_BLOCK; node[u] = idx < ndw ? obs_nodes[idx / (MF_SITES / 4)] : 0; }
+        for (int u = 0; u < 8; u++) { const int idx = i0 + u * MF_BLOCK; node[u] = idx < ndw ? obs_nodes[idx / (sites / 4)] : 0; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int idx = i0 + u * MF_BLOCK, col = idx % (MF_SITES / 4);
+            const int idx = i0 + u * MF_BLOCK, col = idx % (sites / 4);
             q[u] = idx < ndw ? reinterpret_cast<const uint32_t *>(codes + (size_t)node[u] * Spad + site0)[col] : 0u;
         }
 #pragma unroll
@@ -230,6 +230,158 @@ __device__ __forceinline__ void ll_mfma_body(const MfmaArgs &a)
         if (tid == 0) a.partial[blockIdx.x] = r;
     }
 }
+
+/*
+ * The same kernel with TWO groups of 16 sites per wave (round 3; opt-in, PLK_OPT_MFMA_NS2 = 1: measured equal to the
+ * one-group kernel at BASELINE config 5, 5.79 against 5.62 ms -- profiles/r03_exp_codon_kernel_variants.json): every A
+ * fragment read from LDS feeds two matrix-core
+ * instructions, a staged matrix (two workgroup barriers, 30 KB from L2 at k = 61) serves 128 sites instead of 64, and
+ * the two groups' accumulation chains alternate in the matrix pipe.  Site of group j: block * 128 + 64 j + 16 wave + lane % 16;
+ * staged code rows are 128 bytes; the stack slots keep the lane-linear layout (group j at + 256 j).
+ */
+template <int T>
+__device__ __forceinline__ void ll_mfma_body2(const MfmaArgs &a)
+{
+    extern __shared__ double lds_frag[];          /* T * kk4 * 64 doubles, then nobs x 128 staged pattern codes */
+    constexpr int R = 4 * T, NS = 2, SITES = NS * MF_SITES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;
+    const int nfrag = T * a.kk4 * 64;
+    uint8_t *code_lds = reinterpret_cast<uint8_t *>(lds_frag + nfrag);
+    mf_stage_codes(code_lds, a.codes, a.obs_nodes, a.nobs, a.Spad, (size_t)blockIdx.x * SITES, tid, SITES);
+    __syncthreads();
+    const int scol = wave * 16 + (lane & 15);
+    long site[NS], lin[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        site[j] = (long)blockIdx.x * SITES + j * MF_SITES + scol;
+        lin[j] = ((long)blockIdx.x * SITES + j * MF_SITES + wave * 16) * 4 + lane;
+    }
+    double sum[NS] = {0.0, 0.0};
+    int Eexp[NS] = {0, 0};
+    bool have[NS] = {false, false};
+    MfPending pend;
+    mf_request(pend, a.frag + (size_t)(a.first_mv >= 0 ? a.first_mv : 0) * nfrag, nfrag, tid);
+
+    for (int c = 0; c < a.C; c++) {
+        double x[NS][R];
+#pragma unroll
+        for (int j = 0; j < NS; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) x[j][r] = 1.0;
+        int esc[NS] = {0, 0};
+        for (int pc = 0; pc < a.nops; pc++) {
+            int4 op;
+            op.x = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc];
+            op.y = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 1];
+            op.z = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 2];
+            op.w = as_uniform(reinterpret_cast<const int *>(a.ops))[4 * pc + 3];
+            const int code = op.x & 0xff;
+            if (code == OP_MATVEC) {
+                mf_commit(lds_frag, pend, nfrag, tid);
+                const int nc = op.z <= pc ? c + 1 : c;
+                mf_request(pend, a.frag + ((size_t)(nc < a.C ? nc : c) * a.nops + op.z) * nfrag, nfrag, tid);
+                plk_d4 acc[NS][T];
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+#pragma unroll
+                    for (int t = 0; t < T; t++) acc[j][t] = (plk_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if (q < a.kk4) {
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const double af = lds_frag[(t * a.kk4 + q) * 64 + lane];
+#pragma unroll
+                            for (int j = 0; j < NS; j++) acc[j][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, x[j][q], acc[j][t], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        x[j][4 * t + 0] = acc[j][t][0]; x[j][4 * t + 1] = acc[j][t][1];
+                        x[j][4 * t + 2] = acc[j][t][2]; x[j][4 * t + 3] = acc[j][t][3];
+                    }
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL || code == OP_NODE_MUL) {
+                const int t = code == OP_NODE_MUL ? a.ntips : (op.x >> 8);
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    const int ch = code_lds[op.y * SITES + j * MF_SITES + scol];
+                    const double2 *tp = reinterpret_cast<const double2 *>(
+                        a.tip + ((((size_t)c * (a.ntips + 1) + t) * a.nchar + ch) * 4 + g) * R);
+                    if (code == OP_TIP_SET) {
+#pragma unroll
+                        for (int r = 0; r < R; r += 2) { const double2 v = tp[r >> 1]; x[j][r] = v.x; x[j][r + 1] = v.y; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; r += 2) { const double2 v = tp[r >> 1]; x[j][r] *= v.x; x[j][r + 1] *= v.y; }
+                    }
+                }
+            } else if (code == OP_PUSH) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    double *sp = a.slots + (size_t)op.y * R * a.slot_stride + lin[j];
+#pragma unroll
+                    for (int r = 0; r < R; r++) sp[(size_t)r * a.slot_stride] = x[j][r];
+                }
+            } else if (code == OP_POPMUL) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    const double *sp = a.slots + (size_t)op.y * R * a.slot_stride + lin[j];
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[j][r] *= sp[(size_t)r * a.slot_stride];
+                }
+            } else if (code == OP_SCALE) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    double m = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) m = fmax(m, x[j][r]);
+                    m = fmax(m, __shfl_xor(m, 16, 64));
+                    m = fmax(m, __shfl_xor(m, 32, 64));
+                    const int e = frexp_exp(m);
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[j][r] = ldexp(x[j][r], -e);
+                    esc[j] += e;
+                }
+            }
+        }
+        const double *rw = a.root_wd + g * R;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            double lh = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; r++) lh = fma(rw[r], x[j][r], lh);
+            lh += __shfl_xor(lh, 16, 64);
+            lh += __shfl_xor(lh, 32, 64);
+            const double term = as_uniform(a.cat_prior)[c] * lh;
+            if (term != 0.0) {
+                if (!have[j]) { sum[j] = term; Eexp[j] = esc[j]; have[j] = true; }
+                else if (esc[j] > Eexp[j]) { sum[j] = ldexp(sum[j], Eexp[j] - esc[j]) + term; Eexp[j] = esc[j]; }
+                else sum[j] += ldexp(term, esc[j] - Eexp[j]);
+            }
+        }
+    }
+    dd v = dd_make(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const double ll = have[j] ? log(sum[j]) + (double)Eexp[j] * 0.6931471805599453094 : -INFINITY;
+        if (site[j] < a.S && g == 0) {
+            if (a.site_ll) a.site_ll[site[j]] = ll;
+            v = dd_add(v, a.w ? dd_two_prod(a.w[site[j]], ll) : dd_make(ll, 0.0));
+        }
+    }
+    if (a.partial) {
+        dd r = dd_block_sum(v);
+        if (tid == 0) a.partial[blockIdx.x] = r;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ll_mfma_ns2(MfmaArgs a) { ll_mfma_body2<T>(a); }
 
 template <int T>
 __global__ __launch_bounds__(MF_BLOCK) void k_ll_mfma(MfmaArgs a) { ll_mfma_body<T>(a); }

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("PHYLY_AMD_LIB") or os.path.join(_HERE, "csrc", "libar
 HOST, DEVICE = 0, 1
 ROOT_NONE, ROOT_CUSTOM, ROOT_UNIFORM, ROOT_EQUILIBRIUM = 1, 2, 3, 4
 INFO_LL_KERNEL, INFO_STACK_SLOTS, INFO_PROGRAM_OPS, INFO_LL_KERNEL_NS, INFO_LL_TOTAL_NS, INFO_LL_KERNEL_NS_SUM, INFO_LL_KERNEL_COUNT, INFO_LL_VARIANT, INFO_PAIR_TABLES, INFO_LL_EXEC_FLOPS = range(10)
-OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA, OPT_UP_NODES, OPT_PAIR_TABLES, OPT_VEC_REG_STACK = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_FORCE_GENERIC, OPT_SITE_CHUNK, OPT_FUSED_NS, OPT_FUSED_ASM, OPT_MFMA, OPT_UP_NODES, OPT_PAIR_TABLES, OPT_VEC_REG_STACK, OPT_MFMA_NS2 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 COEF_PRIOR, COEF_PRIOR_RATE_EDGE, COEF_PRIOR_RATE = 0, 1, 2
 FIT_EM, FIT_LBFGS = 0, 1
 

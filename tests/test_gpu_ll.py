@@ -187,3 +187,23 @@ def test_vector_kernel_pair_tables_equal_the_plain_program(oracle, T, k, S):
     want = oracle_site_ll(oracle, wl, codes)
     for opt in (1, 0):
         assert np.max(np.abs(out[opt] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12, opt
+
+
+def test_matrix_core_kernel_with_two_site_groups_per_wave(oracle):
+    """PLK_OPT_MFMA_NS2 = 1 (opt-in): k_ll_mfma_ns2, 128 sites per workgroup, against the default kernel and the oracle"""
+    from phyly_amd import engine as E, synth
+    wl = synth.Workload(5)
+    eng = E.Engine(0)
+    wl.setup_engine(eng)
+    codes = wl.random_codes(333, seed=8, missing_frac=0.1)
+    out = {}
+    for opt in (0, 1):
+        eng.set_option(E.OPT_MFMA_NS2, opt)
+        eng.set_patterns_codes(codes, wl.defs)
+        ll, _ = eng.ll()
+        assert eng.info(E.INFO_LL_KERNEL) == 3
+        out[opt] = ll
+    eng.close()
+    want = oracle_site_ll(oracle, wl, codes)
+    assert np.array_equal(out[0], out[1])
+    assert np.max(np.abs(out[1] - want) / np.maximum(1.0, np.abs(want))) <= 1e-12
