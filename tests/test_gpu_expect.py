@@ -263,7 +263,7 @@ def _random_query(rng, kind):
 def test_random_inputs_match_oracle(oracle, kind):
     rng = random.Random({"dwell": 44, "trans": 55, "em_update": 66}[kind])
     done = 0
-    ncases = {"dwell": 40, "trans": 25, "em_update": 40}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
+    ncases = {"dwell": 30, "trans": 25, "em_update": 30}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
     for case in range(ncases):
         x = _random_query(rng, kind)
         s = json.dumps(x)
