@@ -252,26 +252,46 @@ def main():
     # forces it).
     native = False
     if use_dist and not args.torch_allreduce:
-        ok = 1
-        try:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        def agree(ok):
+            """every rank calls this: True only if all ranks say so (so that no rank is left alone in a collective)"""
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item())
+
+        ok = agree(E.Engine.comm_available())          # local: can this process load RCCL at all?
+        if ok:
+            idb = bytes(128)
             if rank == 0:
-                idt = torch.tensor(list(E.Engine.comm_unique_id()), dtype=torch.uint8, device=dev)
+                try:
+                    idb = E.Engine.comm_unique_id()
+                except Exception as exc:      # noqa: BLE001
+                    sys.stderr.write("bench.py: ncclGetUniqueId failed (%s)\n" % exc)
+                    idb = None
+            idt = torch.tensor(list(idb or bytes(128)), dtype=torch.uint8, device=dev)
             dist.broadcast(idt, 0)
-            eng.comm_init(world, rank, bytes(idt.cpu().tolist()))
+            ok = agree(idb is not None)
+        if ok:
+            try:
+                eng.comm_init(world, rank, bytes(idt.cpu().tolist()))     # collective inside RCCL: every rank is here
+            except Exception as exc:          # noqa: BLE001
+                sys.stderr.write("bench.py: ncclCommInitRank failed on rank %d (%s)\n" % (rank, exc))
+                ok = False
+            ok = agree(ok)
+        if ok:
             t1 = torch.tensor([rank + 1.0, 0.5], dtype=torch.float64, device=dev)
             t2 = t1.clone()
-            eng.allreduce_sum_async(t1.data_ptr(), 2)
+            same = True
+            try:
+                eng.allreduce_sum_async(t1.data_ptr(), 2)
+            except Exception as exc:          # noqa: BLE001
+                sys.stderr.write("bench.py: ncclAllReduce failed on rank %d (%s)\n" % (rank, exc))
+                same = False
             dist.all_reduce(t2, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
-            if not torch.equal(t1, t2):
-                ok = 0
-        except Exception as exc:          # noqa: BLE001 -- any failure means "use the framework's collective"
-            sys.stderr.write("bench.py: native RCCL reduction unavailable on rank %d (%s); using torch.distributed\n" % (rank, exc))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native = bool(flag.item())
+            ok = agree(same and torch.equal(t1, t2))
+        native = ok
+        if not native and rank == 0:
+            sys.stderr.write("bench.py: the engine's RCCL reduction is not usable on every rank; using torch.distributed.all_reduce\n")
     RING = 4
     red = torch.zeros((RING, 2), dtype=torch.float64, device=dev)
     pending = []

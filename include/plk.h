@@ -204,6 +204,7 @@ int plk_hess(plk_engine *h, double *hess_sums_out);
  *   plk_comm_init        collective: every rank calls it with the same id
  *   plk_allreduce_sum_async  in-place sum over ranks of `count` doubles in DEVICE memory, queued on the engine's stream
  */
+int plk_comm_available(void);                 /* 1 when RCCL can be loaded in this process (local, not a collective) */
 int plk_comm_unique_id(unsigned char id_out[128]);
 int plk_comm_init(plk_engine *h, int nranks, int rank, const unsigned char id[128]);
 int plk_allreduce_sum_async(plk_engine *h, double *dev, long count);

@@ -2816,6 +2816,8 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
 /* X1: the reduction step over ranks on RCCL (one process per GPU)         */
 /* ====================================================================== */
 
+extern "C" int plk_comm_available(void) { return rccl_load() ? 1 : 0; }
+
 extern "C" int plk_comm_unique_id(unsigned char id_out[128])
 {
     if (!id_out) return PLK_E_ARG;

@@ -67,6 +67,7 @@ def load_library():
     lib.plk_get_info.argtypes = [vp, ci, ctypes.POINTER(cl)]
     lib.plk_set_option.argtypes = [vp, ci, cl]
     lib.plk_comm_unique_id.argtypes = [vp]
+    lib.plk_comm_available.argtypes = []
     lib.plk_comm_init.argtypes = [vp, ci, ci, vp]
     lib.plk_allreduce_sum_async.argtypes = [vp, vp, cl]
     lib.plk_comm_destroy.argtypes = [vp]
@@ -256,6 +257,11 @@ class Engine:
         return P
 
     # -- one process per GPU: the reduction step on RCCL, queued by the engine on its own stream (include/plk.h)
+    @staticmethod
+    def comm_available():
+        """True when the engine can load RCCL in this process (a local check, no communication)"""
+        return bool(load_library().plk_comm_available())
+
     @staticmethod
     def comm_unique_id():
         """128-byte RCCL id (bytes); made on rank 0 and handed to the other ranks by the caller"""
