@@ -207,7 +207,7 @@ def test_medium_and_large_state_spaces(oracle, k):
     nchar = k + 2
     defs = [[1.0 if j == c else 0.0 for j in range(k)] for c in range(k)] + [[1.0] * k] + \
            [[1.0 if j % 3 == 0 else 0.0 for j in range(k)]]
-    S = 12
+    S = 12 if k < 48 else 6
     data = [[rng.randrange(nchar) if rng.random() < 0.7 else k for _ in range(n_nodes)] for _ in range(S)]
     md = {"edges": edges, "edge_rate_coefficients": [rng.random() * 0.5 + 0.01 for _ in edges], "rate_matrix": Q,
           "rate_divisor": "equilibrium_exit_rate", "root_prior": "equilibrium_distribution",

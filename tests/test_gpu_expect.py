@@ -108,7 +108,7 @@ def _directions(w, rng):
     return out
 
 
-@pytest.mark.parametrize("cfg,S,nreq", [(2, 200, 98), (3, 120, 198), (4, 24, 12), (5, 12, 3)])
+@pytest.mark.parametrize("cfg,S,nreq", [(2, 200, 98), (3, 120, 198), (4, 24, 12), (5, 8, 2)])
 def test_edge_expect_matches_oracle(eng, oracle, cfg, S, nreq):
     """plk_edge_expect (fused k=4 path, MFMA path) against the oracle's Frechet matrices + site evaluator"""
     from phyly_amd import synth
@@ -157,7 +157,7 @@ def test_edge_expect_multi_equals_single_calls(eng, cfg, S, nL):
     eng.set_site_weights(None)
 
 
-@pytest.mark.parametrize("cfg,nreq", [(3, 198), (4, 6), (5, 2)])
+@pytest.mark.parametrize("cfg,nreq", [(3, 198), (4, 6), (5, 1)])
 def test_frechet_matrices_match_oracle(eng, oracle, cfg, nreq):
     """the device double-double block exponential against the binary128 one, entry by entry"""
     from phyly_amd import synth, engine as E
@@ -263,7 +263,7 @@ def _random_query(rng, kind):
 def test_random_inputs_match_oracle(oracle, kind):
     rng = random.Random({"dwell": 44, "trans": 55, "em_update": 66}[kind])
     done = 0
-    ncases = {"dwell": 30, "trans": 25, "em_update": 30}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
+    ncases = {"dwell": 24, "trans": 20, "em_update": 24}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
     for case in range(ncases):
         x = _random_query(rng, kind)
         s = json.dumps(x)
