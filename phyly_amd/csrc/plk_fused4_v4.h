@@ -10,10 +10,13 @@
  * Hence:
  *   - a lane carries two sites (A = its own, B = THREADS sites further in the tile): every op is dispatched once for
  *     128 sites, and the two sites' vector instructions alternate in the issue stream (two independent dependency chains);
- *   - 64-bit op words whose fields are final: the low dword is the handler's byte offset (dispatch = or, mov, swappc),
- *     the high dword holds the LDS offsets of the next table and the code row after next already divided by their
- *     granule (2 scalar instructions instead of 5), built on the host by plk_fused_v4_words (plk_program.h);
- *   - op blocks alternate between two SGPR sets in an unrolled loop (no copies); handlers are 512 bytes apart.
+ *   - 64-bit op words whose fields are final: the low dword is the handler's byte offset, the high dword holds the
+ *     LDS offsets of the next table and the code row after next already divided by their granule (2 scalar
+ *     instructions instead of 5), built on the host by plk_fused_v4_words (plk_program.h);
+ *   - threaded dispatch: no interpreter loop, every handler ends by fetching the next op from a ring of two op
+ *     blocks in SGPRs (s_movrels_b64 indexed by M0) and jumping to its handler -- one taken jump per op instead of
+ *     a call and a return; the last op of a block is a REFILL op that requests the block after next.  Handlers are
+ *     512 bytes apart in a 32 KB aligned table.
  * The assembly text is generated (tools/gen_fused4_v4.py -> plk_fused4_v4_asm.h).
  * Reference semantics: src/evaluate_site_lhood.c:21-57, src/util.c:242-301, src/arbplfll.c:139-170.
  */

@@ -694,8 +694,11 @@ static inline std::string plk_fused_check_pt(int N, const int *ip, const int *ix
  *        (offset / 64 of the code row after next, relative to row 0);  tip_base = LDS byte address of the table image.
  */
 #define PLK_V4_HANDLER_BYTES 512
+#define PLK_V4_HANDLER_SLOTS 64
+#define PLK_V4_REFILL_A 32
+#define PLK_V4_REFILL_B 33
 struct PlkFusedV4 {
-    std::vector<unsigned> words;       /* 2 dwords per op, blocks of 8 ops, the spare block included */
+    std::vector<unsigned> words;       /* 2 dwords per op, blocks of 7 ops + 1 REFILL op, two spare blocks */
     unsigned first_y = 0, first_z = 0, second_z = 0;
 };
 
@@ -705,38 +708,69 @@ static inline bool plk_word_is_obs(unsigned hidx)
            (hidx >= PLK_WORD_SET_POPMUL && hidx < PLK_WORD_SET_POPMUL + 4) || (hidx >= PLK_WORD_SET_PUSH && hidx < PLK_WORD_SET_PUSH + 4);
 }
 
+/* Threaded op stream of k_ll_fused4_v4: blocks of 8 ops = 7 ops of the program + one REFILL op (REFILL_A in even blocks,
+ * REFILL_B in odd ones: the handler that requests the block after next into its own half of the kernel's op ring); the
+ * program's ops up to its END, END padding to the end of that block, then two spare blocks (the ring reads two ahead). */
 static inline void plk_fused_v4_words(const PlkFusedPT &fu, int nchar, int tile, unsigned tip_base, PlkFusedV4 &v4)
 {
     const unsigned tb32 = tip_base / 32, rg = (unsigned)tile / 64;
-    v4.words.assign(fu.words.size() * 2, 0u);
-    for (size_t i = 0; i < fu.words.size(); i++) {
-        const unsigned w = fu.words[i], hidx = w & 31;
-        v4.words[2 * i] = hidx * PLK_V4_HANDLER_BYTES;
-        if (plk_word_is_obs(hidx)) v4.words[2 * i + 1] = ((tb32 + ((w >> 5) & 0x7ff) * (unsigned)nchar) << 16) | ((w >> 16) * rg);
-    }
+    size_t nreal = 0;
+    while (nreal < fu.words.size() && (fu.words[nreal] & 31) != OP_END) nreal++;
+    nreal++;                                                  /* the END itself */
+    const size_t nblocks = (nreal + 6) / 7 + 2;
+    v4.words.assign(nblocks * 16, 0u);
+    size_t src = 0;
+    for (size_t b = 0; b < nblocks; b++)
+        for (int j = 0; j < 8; j++) {
+            unsigned *o = &v4.words[(b * 8 + j) * 2];
+            if (j == 7) { o[0] = (unsigned)((b & 1) ? PLK_V4_REFILL_B : PLK_V4_REFILL_A) * PLK_V4_HANDLER_BYTES; continue; }
+            const unsigned w = src < nreal && src < fu.words.size() ? fu.words[src] : (unsigned)OP_END, hidx = w & 31;
+            src++;
+            o[0] = hidx * PLK_V4_HANDLER_BYTES;
+            if (plk_word_is_obs(hidx)) o[1] = ((tb32 + ((w >> 5) & 0x7ff) * (unsigned)nchar) << 16) | ((w >> 16) * rg);
+        }
     v4.first_y = tb32 + (unsigned)fu.first_unit * (unsigned)nchar;
     v4.first_z = (unsigned)fu.first_row * rg;
     v4.second_z = (unsigned)fu.second_row * rg;
 }
 
-/* the 32-bit program is checked by plk_fused_check_pt; this checks the re-encoding: every field fits its 16 bits, is the
- * 32-bit word's field times its granule, and the byte addresses the kernel forms from it stay inside the launch's LDS */
+/* the 32-bit program is checked by plk_fused_check_pt; this checks the re-encoding: the stream is the program's ops in
+ * order with a REFILL op of the right kind closing every block, an END is reached, two whole blocks follow the block of the
+ * END (what the ring has requested by then), every field fits its 16 bits, is the 32-bit word's field times its granule,
+ * and the byte addresses the kernel forms from it stay inside the launch's LDS */
 static inline std::string plk_fused_check_v4(const PlkFusedPT &fu, const PlkFusedV4 &v4, int nchar, int tile, unsigned tip_base,
                                              size_t lds_bytes_launched)
 {
     if (tip_base % 32 != 0 || tile % 64 != 0) return "v4 program: LDS base or tile granule";
-    if (v4.words.size() != 2 * fu.words.size()) return "v4 program: word count";
+    if (v4.words.size() % 16 != 0 || v4.words.size() < 48) return "v4 program: word count";
     const size_t tip_bytes = (size_t)fu.units * nchar * 32, lds_end = tip_base + lds_bytes_launched;
     const unsigned tb32 = tip_base / 32, rg = (unsigned)tile / 64;
-    auto y_ok = [&](unsigned y, unsigned unit) { return y == tb32 + unit * (unsigned)nchar && y < 65536u && (size_t)y * 32 + (size_t)nchar * nchar * 32 <= lds_end + (size_t)nchar * nchar * 32 && (size_t)y * 32 >= tip_base && (size_t)y * 32 < tip_base + tip_bytes; };
+    auto y_ok = [&](unsigned y, unsigned unit) { return y == tb32 + unit * (unsigned)nchar && y < 65536u && (size_t)y * 32 >= tip_base && (size_t)y * 32 < tip_base + tip_bytes; };
     auto z_ok = [&](unsigned z, unsigned row) { return z == row * rg && z < 65536u && tip_base + tip_bytes + (size_t)z * 64 + (size_t)tile <= lds_end; };
     if (!y_ok(v4.first_y, (unsigned)fu.first_unit) || !z_ok(v4.first_z, (unsigned)fu.first_row) || !z_ok(v4.second_z, (unsigned)fu.second_row)) return "v4 program: prologue fields";
-    for (size_t i = 0; i < fu.words.size(); i++) {
-        const unsigned w = fu.words[i], hidx = w & 31, lo = v4.words[2 * i], hi = v4.words[2 * i + 1];
-        if (lo != hidx * PLK_V4_HANDLER_BYTES || lo >= 32u * PLK_V4_HANDLER_BYTES) return plk_fmt("v4 program: handler offset of op %ld", (long)i);
-        if (!plk_word_is_obs(hidx)) { if (hi != 0) return plk_fmt("v4 program: stray fields in op %ld", (long)i); continue; }
-        if (!y_ok(hi >> 16, (w >> 5) & 0x7ff) || !z_ok(hi & 0xffff, w >> 16)) return plk_fmt("v4 program: fields of op %ld", (long)i);
-    }
+    const size_t nblocks = v4.words.size() / 16;
+    size_t src = 0;
+    long end_block = -1;
+    for (size_t b = 0; b < nblocks; b++)
+        for (int j = 0; j < 8; j++) {
+            const unsigned lo = v4.words[(b * 8 + j) * 2], hi = v4.words[(b * 8 + j) * 2 + 1];
+            if (lo % PLK_V4_HANDLER_BYTES != 0 || lo >= (unsigned)PLK_V4_HANDLER_SLOTS * PLK_V4_HANDLER_BYTES) return plk_fmt("v4 program: handler offset in block %ld", (long)b);
+            const unsigned hidx = lo / PLK_V4_HANDLER_BYTES;
+            if (j == 7) {
+                if (hidx != (unsigned)((b & 1) ? PLK_V4_REFILL_B : PLK_V4_REFILL_A) || hi != 0) return plk_fmt("v4 program: block %ld does not end in its REFILL op", (long)b);
+                continue;
+            }
+            if (hidx >= 32) return plk_fmt("v4 program: REFILL op inside block %ld", (long)b);
+            if (end_block >= 0) { if (hidx != OP_END || hi != 0) return "v4 program: ops after END"; continue; }
+            if (src >= fu.words.size()) return "v4 program: more ops than the program";
+            const unsigned w = fu.words[src++];
+            if (hidx != (w & 31)) return plk_fmt("v4 program: op %ld is not the program's", (long)(src - 1));
+            if (hidx == OP_END) { if (hi != 0) return "v4 program: stray fields in END"; end_block = (long)b; continue; }
+            if (!plk_word_is_obs(hidx)) { if (hi != 0) return plk_fmt("v4 program: stray fields in op %ld", (long)(src - 1)); continue; }
+            if (!y_ok(hi >> 16, (w >> 5) & 0x7ff) || !z_ok(hi & 0xffff, w >> 16)) return plk_fmt("v4 program: fields of op %ld", (long)(src - 1));
+        }
+    if (end_block < 0) return "v4 program: no END";
+    if ((size_t)end_block + 2 >= nblocks) return "v4 program: fewer than two spare blocks after the END";
     return "";
 }
 

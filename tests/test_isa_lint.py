@@ -99,7 +99,7 @@ def test_handler_table_layout_check_accepts_the_build_and_rejects_an_overlong_ha
 
     def table(overlong_slot):
         ins, a = [(0x1ffc, "s_nop")], 0x2000
-        for slot in range(mod.NSLOTS):
+        for slot in range(32):
             n = 70 if slot == overlong_slot else (68 if slot == 4 else 10)     # 4-byte instructions: 70 > 64 per slot
             end = a + 4 * n
             while a < end - 4:

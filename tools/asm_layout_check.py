@@ -8,7 +8,8 @@ disassembles the device object (llvm-objdump) and checks, for every k_ll_fused4_
   - the table (first instruction after the run of s_nop padding that ends on an 8 KB boundary) exists,
   - at every 256-byte boundary inside the table the previous instruction is padding (s_nop) or an unconditional
     transfer (s_setpc_b64 / s_branch), i.e. no handler runs across a boundary -- except between slots 4 and 5,
-  - 32 slots are present.
+  - 32 slots are present (64 slots of 512 bytes on a 32 KB boundary for the two-sites-per-lane interpreter
+    k_ll_fused4_v4, whose handlers end in a threaded dispatch: s_setpc_b64 again).
 
   python tools/asm_layout_check.py build/plk_engine-hip-amdgcn-amd-amdhsa-gfx950.o"""
 import re
@@ -16,9 +17,8 @@ import subprocess
 import sys
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-NSLOTS = 32
-# kernel-name substring -> (bytes per handler slot, table alignment, slot that may run on into the next one or None)
-FAMILIES = {"k_ll_fused4_asm": (256, 0x2000, 4), "k_ll_fused4_v4": (512, 0x4000, None)}
+# kernel-name substring -> (bytes per handler slot, table alignment, slot that may run on into the next one or None, slots)
+FAMILIES = {"k_ll_fused4_asm": (256, 0x2000, 4, 32), "k_ll_fused4_v4": (512, 0x8000, None, 64)}
 
 
 def kernels(obj):
@@ -36,7 +36,7 @@ def kernels(obj):
     return {k: v for k, v in body.items() if any(f in k for f in FAMILIES)}
 
 
-def check(name, ins, slot_bytes=256, align=0x2000, long_slot=4):
+def check(name, ins, slot_bytes=256, align=0x2000, long_slot=4, NSLOTS=32):
     addr = {a: op for a, op in ins}
     order = [a for a, _ in ins]
     # table base: an aligned address whose predecessor is s_nop padding and which is followed by real code
