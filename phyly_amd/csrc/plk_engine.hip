@@ -71,6 +71,7 @@ struct plk_engine {
     double *d_root_w = nullptr;          /* K, zero padded; the weights of the root dot */
     dd *d_Pdd = nullptr;                 /* [C][E][k*k] unrounded */
     double *d_P = nullptr, *d_dP = nullptr; /* [C][E][k][k] rounded; dP = r_c Qn P */
+    bool dp_valid = false;                  /* d_dP holds dP of the current P (K1 skips it for ll evaluations: ensure_dP) */
     dd *d_scratch = nullptr;
     size_t pdd_cap = 0, p_cap = 0, dp_cap = 0, scratch_cap = 0;
     bool model_dirty = true;
@@ -288,6 +289,119 @@ __device__ static void dd_matmul_block(int k, const dd *A, const dd *B, dd *Cm)
     }
 }
 
+/* The same product for matrices that live in global scratch (k > 26: codon models, every Frechet block matrix from
+ * k = 14 up).  One thread per entry (above) sends two 16-byte loads per term through the CU's vector memory path, which
+ * is what bounded K1 at k = 61.  Here a wave owns R rows x 64 columns of the result: it copies its R rows of A into its
+ * own LDS strip once, then per term l every lane loads its B[l][j] (coalesced) and reads the R values A[i0 + r][l] from
+ * the LDS strip (one address for the whole wave: a broadcast) -- 1 vector-memory load per R terms instead of 2 per term.
+ * The sums run over l in the same order with the same Dot2 update, so the result is the one dd_matmul_block gives. */
+#define EXPM_TILE_ROWS 4
+template <int R>
+__device__ static void dd_matmul_tiled(int k, const dd *A, const dd *B, dd *Cm, dd *strips)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    dd *arow = strips + (size_t)wave * EXPM_TILE_ROWS * k;
+    const int ngroups = (k + R - 1) / R, nchunks = (k + 63) / 64;
+    for (int item = wave; item < ngroups * nchunks; item += nw) {
+        const int g = item / nchunks, ch = item - g * nchunks;
+        const int i0 = g * R, j = ch * 64 + lane;
+        __builtin_amdgcn_wave_barrier();                 /* the strip's previous reads are done (same wave: in order) */
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            for (int t = lane; t < k; t += 64) arow[r * k + t] = i0 + r < k ? A[(size_t)(i0 + r) * k + t] : dd_make(0.0, 0.0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool act = j < k;
+        const dd *bcol = B + (act ? j : 0);
+        double sh[R], sl[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { sh[r] = 0.0; sl[r] = 0.0; }
+#pragma unroll 2
+        for (int l = 0; l < k; l++) {
+            const dd b = bcol[(size_t)l * k];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const dd a = arow[r * k + l];
+                const double p = a.hi * b.hi;
+                double e = fma(a.hi, b.hi, -p);
+                e = fma(a.hi, b.lo, e);
+                e = fma(a.lo, b.hi, e);
+                const double t = sh[r] + p, bb = t - sh[r];
+                sl[r] += ((sh[r] - (t - bb)) + (p - bb)) + e;
+                sh[r] = t;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (i0 + r < k) Cm[(size_t)(i0 + r) * k + j] = dd_quick_two_sum(sh[r], sl[r]);
+        }
+    }
+}
+
+/* strips == nullptr: the buffers are in LDS (small k), one thread per entry */
+__device__ static void dd_matmul(int k, const dd *A, const dd *B, dd *Cm, dd *strips)
+{
+    if (!strips) { dd_matmul_block(k, A, B, Cm); return; }
+    const int nw = blockDim.x >> 6;
+    if (((k + 3) / 4) * ((k + 63) / 64) >= nw) dd_matmul_tiled<4>(k, A, B, Cm, strips);
+    else dd_matmul_tiled<2>(k, A, B, Cm, strips);
+}
+
+/* dP = r_c Qn P, rounded, every entry a double-double sum over l in order (src/util.c:338-345 is what reads it);
+ * strips as for dd_matmul: null = one thread per entry, else a wave owns 4 rows x 64 columns and keeps its rows of Qn in LDS */
+__device__ static void dd_rate_product(int k, const double *__restrict__ Qn /* [2][k*k] */, const dd *O, double rc, double *dPout, dd *strips)
+{
+    const int kk = k * k;
+    if (!strips) {
+        for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) {
+            const int i = idx / k, j = idx - i * k;
+            dd acc = dd_make(0.0, 0.0);
+            for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(O[l * k + j], dd_make(Qn[i * k + l], Qn[kk + i * k + l])));
+            dPout[idx] = dd_mul_d(acc, rc).hi;
+        }
+        return;
+    }
+    constexpr int R = EXPM_TILE_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    dd *arow = strips + (size_t)wave * R * k;
+    const int ngroups = (k + R - 1) / R, nchunks = (k + 63) / 64;
+    for (int item = wave; item < ngroups * nchunks; item += nw) {
+        const int g = item / nchunks, ch = item - g * nchunks;
+        const int i0 = g * R, j = ch * 64 + lane;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            for (int t = lane; t < k; t += 64)
+                arow[r * k + t] = i0 + r < k ? dd_make(Qn[(i0 + r) * k + t], Qn[kk + (i0 + r) * k + t]) : dd_make(0.0, 0.0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool act = j < k;
+        const dd *bcol = O + (act ? j : 0);
+        dd acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = dd_make(0.0, 0.0);
+        for (int l = 0; l < k; l++) {
+            const dd b = bcol[(size_t)l * k];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = dd_add(acc[r], dd_mul(b, arow[r * k + l]));
+        }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (i0 + r < k) dPout[(size_t)(i0 + r) * k + j] = dd_mul_d(acc[r], rc).hi;
+        }
+    }
+}
+
+/* dynamic LDS of a k_expm_dd launch on kdim x kdim matrices: the six buffers, or one strip of rows per wave */
+static inline size_t expm_lds_bytes(size_t kdim, int threads, int *use_lds)
+{
+    const size_t buffers = 6 * kdim * kdim * sizeof(dd);
+    *use_lds = buffers <= 64 * 1024;
+    return *use_lds ? buffers : (size_t)(threads / 64) * EXPM_TILE_ROWS * kdim * sizeof(dd);
+}
+
 #define EXPM_TERMS 16     /* with |A| <= 2^-5 after scaling: 2^-80 / 16! < 1e-37, below double-double resolution */
 /* The degree-16 Taylor polynomial is evaluated by Paterson-Stockmeyer: powers A^2, A^3, A^4 (three products), then
  * Horner in A^4 over the four cubic blocks B_i = c_4i I + c_4i+1 A + c_4i+2 A^2 + c_4i+3 A^3 (three more products) --
@@ -309,6 +423,7 @@ struct ExpmPost {
     int nmat1, ntips1, nchar;  /* matrices / tip slots per category (incl. the spare / pseudo one), definitions */
     const double *defs;        /* [nchar][4] */
     double *PS, *tip;
+    int skip_dP;               /* an ll evaluation does not read dP: k_dP_dd makes it when a derivative asks (ensure_dP) */
 };
 
 template <bool FRECHET>
@@ -333,6 +448,7 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
         return;
     }
     dd *base = use_lds ? reinterpret_cast<dd *>(smem_raw) : gscratch + (size_t)ce * EXPM_BUFFERS * kk;
+    dd *strips = use_lds ? nullptr : reinterpret_cast<dd *>(smem_raw);       /* global buffers: row strips of the tiled product */
     dd *X = base, *X2 = base + kk, *O = base + 2 * kk, *W = base + 3 * kk, *X3 = base + 4 * kk, *X4 = base + 5 * kk;
 
     const dd s = dd_two_prod(cat_rates[c], edge_rates[e]);
@@ -370,10 +486,10 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
     const int sq = s_sq;
     for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) X[idx] = dd_ldexp(X[idx], -sq);
     __syncthreads();
-    dd_matmul_block(k, X, X, X2);
+    dd_matmul(k, X, X, X2, strips);
     __syncthreads();
-    dd_matmul_block(k, X2, X, X3);
-    dd_matmul_block(k, X2, X2, X4);
+    dd_matmul(k, X2, X, X3, strips);
+    dd_matmul(k, X2, X2, X4, strips);
     __syncthreads();
     /* cubic block i of the polynomial at entry idx */
     auto block = [&](int ib, int idx) -> dd {
@@ -385,13 +501,13 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
     for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = dd_add(block(3, idx), dd_mul(s_coef[16], X4[idx]));
     __syncthreads();
     for (int ib = 2; ib >= 0; ib--) {
-        dd_matmul_block(k, X4, O, W);
+        dd_matmul(k, X4, O, W, strips);
         __syncthreads();
         for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = dd_add(block(ib, idx), W[idx]);
         __syncthreads();
     }
     for (int q = 0; q < sq; q++) {
-        dd_matmul_block(k, O, O, W);
+        dd_matmul(k, O, O, W, strips);
         __syncthreads();
         for (int idx = threadIdx.x; idx < kk; idx += blockDim.x) O[idx] = W[idx];
         __syncthreads();
@@ -413,11 +529,11 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
         if (v.hi < 0) v = dd_make(0.0, 0.0);
         Pdd[(size_t)ce * kk + idx] = v;
         P[(size_t)ce * kk + idx] = v.hi;
-        int i = idx / k, j = idx - i * k;
-        dd acc = dd_make(0.0, 0.0);
-        for (int l = 0; l < k; l++) acc = dd_add(acc, dd_mul(O[l * k + j], dd_make(Qn[i * k + l], Qn[kk + i * k + l])));
-        acc = dd_mul_d(acc, rc);
-        dP[(size_t)ce * kk + idx] = acc.hi;
+    }
+    if (!post.skip_dP) {
+        /* from the clamped matrix, as k_dP_dd computes it later from Pdd: one definition of dP whichever kernel wrote it */
+        __syncthreads();
+        dd_rate_product(k, Qn, Pdd + (size_t)ce * kk, rc, dP + (size_t)ce * kk, strips);
     }
     if (!FRECHET && post.edge_slot && k == 4) {
         const int mi = post.edge_slot[e], t = post.edge_slot[E + e];
@@ -446,6 +562,16 @@ __global__ __launch_bounds__(1024) void k_expm_dd(int ks, int E, const double *_
                 post.tip[(((size_t)c * post.ntips1 + t) * post.nchar + code) * 4 + i] = out;
             }
     }
+}
+
+/* dP = r_c Qn P for every (category, edge) from the stored double-double P: what K1 skips for an ll evaluation */
+__global__ __launch_bounds__(1024) void k_dP_dd(int k, int E, const double *__restrict__ Qn, const double *__restrict__ cat_rates,
+                                                const dd *__restrict__ Pdd, double *__restrict__ dP, int tiled)
+{
+    extern __shared__ double smem_raw[];
+    const int ce = blockIdx.x, c = ce / E;
+    const size_t kk = (size_t)k * k;
+    dd_rate_product(k, Qn, Pdd + ce * kk, cat_rates[c], dP + ce * kk, tiled ? reinterpret_cast<dd *>(smem_raw) : nullptr);
 }
 
 /* PS[c][pc][j*K + i] = P[c][edge(pc)][i][j], zero padded to K (transposed so that
@@ -1357,7 +1483,7 @@ extern "C" int plk_set_tree(plk_engine *h, int N, const int *indptr, const int *
     return PLK_OK;
 }
 
-static int run_expm(plk_engine *h, bool post = false)
+static int run_expm(plk_engine *h, bool post = false, bool need_dP = true)
 {
     const int k = h->k, C = h->C, E = h->E;
     const size_t kk = (size_t)k * k, n = (size_t)C * E * kk;
@@ -1365,11 +1491,11 @@ static int run_expm(plk_engine *h, bool post = false)
     if ((rc = dev_reserve(h, &h->d_Pdd, &h->pdd_cap, n))) return rc;
     if ((rc = dev_reserve(h, &h->d_P, &h->p_cap, n))) return rc;
     if ((rc = dev_reserve(h, &h->d_dP, &h->dp_cap, n))) return rc;
-    const size_t lds_bytes = EXPM_BUFFERS * kk * sizeof(dd);
-    const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * EXPM_BUFFERS * kk))) return rc; }
     /* one thread per few matrix entries: the dd matrix products are the whole cost for k = 61 */
     const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
+    int use_lds;
+    const size_t lds_bytes = expm_lds_bytes((size_t)k, threads, &use_lds);
+    if (!use_lds) { if ((rc = dev_reserve(h, &h->d_scratch, &h->scratch_cap, (size_t)C * E * EXPM_BUFFERS * kk))) return rc; }
     ExpmPost ep = {};
     post = post && k == 4 && h->fmt_kind == 1 && !h->fmt_dirty && h->d_edge_slot;
     if (post) {
@@ -1377,7 +1503,8 @@ static int run_expm(plk_engine *h, bool post = false)
         ep.nchar = h->nchar; ep.defs = h->d_defs; ep.PS = h->d_PS; ep.tip = h->d_tip;
         if (h->fmt_pt) { ep.nmat1 = (int)h->fpt.mat_edge.size() + 1; ep.ntips1 = h->fpt.units; }    /* no tip slots in edge_slot: tables below */
     }
-    hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+    ep.skip_dP = need_dP ? 0 : 1;
+    hipLaunchKernelGGL(k_expm_dd<false>, dim3(C * E), dim3(threads), lds_bytes, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, h->d_Pdd, h->d_P, h->d_dP,
                        h->d_scratch, use_lds, (const double *)nullptr, 0, (const int *)nullptr, (double *)nullptr, ep);
     HIPCHK(h, hipGetLastError());
@@ -1388,7 +1515,24 @@ static int run_expm(plk_engine *h, bool post = false)
         HIPCHK(h, hipGetLastError());
     }
     h->model_dirty = false;
+    h->dp_valid = need_dP;
     h->tables_dirty = !post;
+    return PLK_OK;
+}
+
+/* the derivative paths read dP; an ll evaluation at new rates leaves it to the first of them */
+static int ensure_dP(plk_engine *h)
+{
+    if (h->dp_valid || h->E == 0) return PLK_OK;
+    const int k = h->k;
+    const size_t kk = (size_t)k * k;
+    const int threads = kk >= 1024 ? 1024 : (kk >= 256 ? 256 : 64);
+    int use_lds;
+    const size_t strip_bytes = expm_lds_bytes((size_t)k, threads, &use_lds);
+    hipLaunchKernelGGL(k_dP_dd, dim3(h->C * h->E), dim3(threads), use_lds ? 0 : strip_bytes, h->stream,
+                       k, h->E, h->d_Qn, h->d_cat_rates, h->d_Pdd, h->d_dP, use_lds ? 0 : 1);
+    HIPCHK(h, hipGetLastError());
+    h->dp_valid = true;
     return PLK_OK;
 }
 
@@ -1861,7 +2005,7 @@ static int ll_impl(plk_engine *h, double *site_ll_out, int where, double *sum_ou
     const bool vec = !fused && use_vec(h), mfma = !fused && !vec && use_mfma(h) && mfma_ll_lds_bytes(h) <= PLK_LDS_LIMIT;
     const long kind = fused ? 1 : (vec ? 4 : (mfma ? 3 : 2));
     if (h->fmt_dirty || kind != h->fmt_kind) { if ((rc = upload_formats(h, kind))) return rc; }
-    if (h->model_dirty) { if ((rc = run_expm(h, true))) return rc; }      /* K1; for k = 4 it writes the stream and tip tables too */
+    if (h->model_dirty) { if ((rc = run_expm(h, true, false))) return rc; }      /* K1 without dP; for k = 4 it writes the stream and tip tables too */
     if (h->tables_dirty) { if ((rc = build_tables(h, kind))) return rc; }
     const bool want_sum = sum_out || sum_dev;
     const long S = h->S;
@@ -2707,6 +2851,7 @@ static int run_updown(plk_engine *h, bool deriv, bool marg, const int *edge_mask
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    if (!d_M_in && (rc = ensure_dP(h))) return rc;
     const double *d_M = d_M_in ? d_M_in : h->d_dP;
     if (use_updown_vec(h) && nM == 1) return run_updown_vec(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
     if (use_mfma(h)) return run_updown_mfma(h, deriv, marg, edge_mask, node_mask, site_out, sums_out, d_M, dzero);
@@ -2891,8 +3036,9 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
     const int per_pass = use_updown4(h) && !use_mfma(h) ? 4 : 1;
     /* grow-only engine buffers: no per-call hipMalloc / hipFree */
     auto cleanup = [&]() {};
-    const size_t lds_bytes = EXPM_BUFFERS * n2 * sizeof(dd);
-    const int use_lds = lds_bytes <= 64 * 1024;
+    const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
+    int use_lds;
+    const size_t lds_bytes = expm_lds_bytes((size_t)2 * k, threads, &use_lds);
     if ((rc = dev_reserve(h, &h->d_exL, &h->exL_cap, (size_t)per_pass * 2 * kk)) ||
         (rc = dev_reserve(h, &h->d_exF, &h->exF_cap, (size_t)per_pass * C * E * kk)) ||
         (rc = dev_reserve(h, &h->d_exmask, &h->exmask_cap, (size_t)E)) ||
@@ -2904,7 +3050,6 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
         HIPCHK(h, hipMemcpyAsync(h->d_exmask, edge_mask, (size_t)E * sizeof(int), hipMemcpyHostToDevice, h->stream));
         d_mask = h->d_exmask;
     }
-    const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
     std::vector<double> L((size_t)per_pass * 2 * kk), tmp_site, tmp_sums;
     for (int m0 = 0; m0 < nL; m0 += per_pass) {
         const int nm = std::min(per_pass, nL - m0);
@@ -2917,7 +3062,7 @@ extern "C" int plk_edge_expect_multi(plk_engine *h, int nL, const double *L_hi, 
         HIPCHK(h, hipStreamSynchronize(h->stream));          /* the previous pass may still read d_L */
         HIPCHK(h, hipMemcpyAsync(d_L, L.data(), (size_t)nm * 2 * kk * sizeof(double), hipMemcpyHostToDevice, h->stream));
         for (int m = 0; m < nm; m++) {
-            hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+            hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), lds_bytes, h->stream,
                                k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
                                d_scr, use_lds, d_L + (size_t)m * 2 * kk, coef_mode, d_mask, d_F + (size_t)m * C * E * kk, ExpmPost{});
         }
@@ -2968,11 +3113,11 @@ extern "C" int plk_get_frechet_matrices(plk_engine *h, const double *L_hi, const
         if (d_scr) (void)hipFree(d_scr);
     };
     if ((rc = dev_upload(h, &d_L, L.data(), L.size())) || (rc = dev_alloc(h, &d_F, (size_t)C * E * kk))) { cleanup(); return rc; }
-    const size_t lds_bytes = EXPM_BUFFERS * n2 * sizeof(dd);
-    const int use_lds = lds_bytes <= 64 * 1024;
-    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * EXPM_BUFFERS * n2))) { cleanup(); return rc; }
     const int threads = n2 >= 1024 ? 1024 : (n2 >= 256 ? 256 : 64);
-    hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), use_lds ? lds_bytes : 0, h->stream,
+    int use_lds;
+    const size_t lds_bytes = expm_lds_bytes((size_t)2 * k, threads, &use_lds);
+    if (!use_lds && (rc = dev_alloc(h, &d_scr, (size_t)C * E * EXPM_BUFFERS * n2))) { cleanup(); return rc; }
+    hipLaunchKernelGGL(k_expm_dd<true>, dim3(C * E), dim3(threads), lds_bytes, h->stream,
                        k, E, h->d_Qn, h->d_edge_rates, h->d_cat_rates, (dd *)nullptr, (double *)nullptr, (double *)nullptr,
                        d_scr, use_lds, d_L, coef_mode, (const int *)nullptr, d_F, ExpmPost{});
     hipError_t e = hipGetLastError();
@@ -3226,6 +3371,7 @@ extern "C" int plk_hess(plk_engine *h, double *hess_sums_out /* [E][E][2] */)
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (h->model_dirty) { if ((rc = run_expm(h))) return rc; }
+    if ((rc = ensure_dP(h))) return rc;
     const int N = h->N, E = h->E, k = h->k, K = h->K, C = h->C;
     const long S = h->S;
     const size_t kk = (size_t)k * k, strm = (size_t)C * E * K * K;

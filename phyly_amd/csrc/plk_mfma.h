@@ -410,14 +410,33 @@ __global__ void k_build_frag(int k, int T, int kk4, int E, int nops, const int *
 }
 
 /* distributed tip tables: tip[(((c*(ntips+1) + t)*nchar + code)*4 + g)*R + r] = (P_e defs[code])[g + 4r]
- * (dd accumulation; exact for constant definition rows; slot ntips holds defs[code] itself) */
+ * (dd accumulation; exact for constant definition rows; slot ntips holds defs[code] itself).  A definition row that is
+ * zero except for one 1.0 (an observed state: all but a few rows of a real alphabet) selects a column of P_e: the
+ * double-double sum then has one non-zero term and returns it unchanged, so the column is copied instead of summed
+ * (the same bits, 1/k of the work: 262 -> see profiles/r03_exp_codon_kernel_variants.json). */
+#define PLK_DEF_KIND_CACHE 1024
+__device__ static inline int def_row_kind(const double *d, int k)
+{
+    bool constant = true;
+    int nnz = 0, at = -1;
+    for (int j = 0; j < k; j++) {
+        constant = constant && (d[j] == d[0]);
+        if (d[j] != 0.0) { nnz++; at = j; }
+    }
+    if (constant) return -2;                    /* src/util.c:276-283: a constant row maps to itself */
+    return nnz == 1 && d[at] == 1.0 ? at : -1;
+}
+
 __global__ void k_build_tip_dist(int k, int R, int E, int ntips, int nchar, const int *__restrict__ tip_edge,
                                  const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][K] */, int Kpad,
                                  double *__restrict__ tip)
 {
+    __shared__ int s_kind[PLK_DEF_KIND_CACHE];
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
     const int n = nchar * 4 * R;
+    for (int code = threadIdx.x; code < nchar && code < PLK_DEF_KIND_CACHE; code += blockDim.x) s_kind[code] = def_row_kind(defs + (size_t)code * Kpad, k);
+    __syncthreads();
     for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
         const int r = idx % R, gq = idx / R;
         const int g = gq & 3, code = gq >> 2;
@@ -427,11 +446,11 @@ __global__ void k_build_tip_dist(int k, int R, int E, int ntips, int nchar, cons
         if (i < k) {
             if (e < 0) out = d[i];
             else {
-                bool constant = true;
-                for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
-                if (constant) out = d[0];
+                const int kind = code < PLK_DEF_KIND_CACHE ? s_kind[code] : def_row_kind(d, k);
+                const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                if (kind == -2) out = d[0];
+                else if (kind >= 0) out = Pm[kind].hi;
                 else {
-                    const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
                     dd acc = dd_make(0.0, 0.0);
                     for (int j = 0; j < k; j++) acc = dd_add(acc, dd_mul_d(Pm[j], d[j]));
                     out = acc.hi;

@@ -677,9 +677,12 @@ __global__ void k_build_dtip_dist(int k, int R, int E, int ntips, int nchar, con
                                   const double *__restrict__ dP, const double *__restrict__ defs, int Kpad,
                                   double *__restrict__ dtip, int dzero)
 {
+    __shared__ int s_kind[PLK_DEF_KIND_CACHE];
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
     const int nn = nchar * 4 * R;
+    for (int code = threadIdx.x; code < nchar && code < PLK_DEF_KIND_CACHE; code += blockDim.x) s_kind[code] = def_row_kind(defs + (size_t)code * Kpad, k);
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
         const int r = idx % R, gq = idx / R;
         const int g = gq & 3, code = gq >> 2;
@@ -687,13 +690,15 @@ __global__ void k_build_dtip_dist(int k, int R, int E, int ntips, int nchar, con
         const double *d = defs + (size_t)code * Kpad;
         double out = 0.0;
         if (i < k && e >= 0) {
-            bool constant = true;
-            for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
-            if (!(constant && dzero)) {
+            const int kind = code < PLK_DEF_KIND_CACHE ? s_kind[code] : def_row_kind(d, k);
+            if (!(kind == -2 && dzero)) {
                 const double *row = dP + ((size_t)c * E + e) * k * k + (size_t)i * k;
-                dd acc = dd_make(0.0, 0.0);
-                for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
-                out = acc.hi;
+                if (kind >= 0) out = row[kind];             /* an observed state: column `kind` of dP_e (one non-zero term, exact) */
+                else {
+                    dd acc = dd_make(0.0, 0.0);
+                    for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
+                    out = acc.hi;
+                }
             }
         }
         dtip[(((size_t)c * (ntips + 1) + t) * nchar + code) * 4 * R + (size_t)g * R + r] = out;

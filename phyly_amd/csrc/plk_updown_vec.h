@@ -462,20 +462,25 @@ __global__ void k_build_dtip_vec(int k, int K, int E, int ntips, int nchar, cons
                                  const double *__restrict__ M /* [C][E][k][k] */, const double *__restrict__ defs /* [nchar][Kdef] */,
                                  int Kdef, double *__restrict__ dtip, int dzero)
 {
+    __shared__ int s_kind[PLK_DEF_KIND_CACHE];
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
+    for (int code = threadIdx.x; code < nchar && code < PLK_DEF_KIND_CACHE; code += blockDim.x) s_kind[code] = def_row_kind(defs + (size_t)code * Kdef, k);
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nchar * K; idx += blockDim.x) {
         const int code = idx / K, i = idx - code * K;
         const double *d = defs + (size_t)code * Kdef;
         double out = 0.0;
         if (i < k && e >= 0) {
-            bool constant = true;
-            for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
-            if (!(constant && dzero)) {
+            const int kind = code < PLK_DEF_KIND_CACHE ? s_kind[code] : def_row_kind(d, k);
+            if (!(kind == -2 && dzero)) {
                 const double *row = M + ((size_t)c * E + e) * k * k + (size_t)i * k;
-                dd acc = dd_make(0.0, 0.0);
-                for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
-                out = acc.hi;
+                if (kind >= 0) out = row[kind];             /* an observed state: column `kind` of M_e (one non-zero term, exact) */
+                else {
+                    dd acc = dd_make(0.0, 0.0);
+                    for (int j = 0; j < k; j++) acc = dd_add(acc, dd_two_prod(row[j], d[j]));
+                    out = acc.hi;
+                }
             }
         }
         dtip[(((size_t)c * (ntips + 1) + t) * nchar + code) * K + i] = out;

@@ -301,8 +301,11 @@ __global__ void k_build_tip_vec(int k, int K, int E, int ntips, int nchar, const
                                 const dd *__restrict__ Pdd, const double *__restrict__ defs /* [nchar][K] */,
                                 double *__restrict__ tip)
 {
+    __shared__ int s_kind[PLK_DEF_KIND_CACHE];
     const int t = blockIdx.x, c = blockIdx.y;
     const int e = tip_edge[t];
+    for (int code = threadIdx.x; code < nchar && code < PLK_DEF_KIND_CACHE; code += blockDim.x) s_kind[code] = def_row_kind(defs + (size_t)code * K, k);
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nchar * K; idx += blockDim.x) {
         const int code = idx / K, i = idx - code * K;
         const double *d = defs + (size_t)code * K;
@@ -310,11 +313,12 @@ __global__ void k_build_tip_vec(int k, int K, int E, int ntips, int nchar, const
         if (i < k) {
             if (e < 0) out = d[i];
             else {
-                bool constant = true;
-                for (int j = 1; j < k; j++) constant = constant && (d[j] == d[0]);
-                if (constant) out = d[0];
+                /* constant rows map to themselves, observed-state rows copy a column of P_e (def_row_kind, plk_mfma.h) */
+                const int kind = code < PLK_DEF_KIND_CACHE ? s_kind[code] : def_row_kind(d, k);
+                const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
+                if (kind == -2) out = d[0];
+                else if (kind >= 0) out = Pm[kind].hi;
                 else {
-                    const dd *Pm = Pdd + ((size_t)c * E + e) * k * k + (size_t)i * k;
                     dd acc = dd_make(0.0, 0.0);
                     for (int j = 0; j < k; j++) acc = dd_add(acc, dd_mul_d(Pm[j], d[j]));
                     out = acc.hi;
