@@ -2556,9 +2556,21 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         pair_tabs.insert(pair_tabs.end(), t_eb.begin(), t_eb.end());
         pair_tabs.insert(pair_tabs.end(), t_ec.begin(), t_ec.end());
     }
+    /* One level up: a node whose two children are leaves or pair nodes has L = (row of one table) o (row of another).  The
+     * down pass does not store it and the node-visit up pass multiplies the two rows (plk_up_rebuild_table; PLK_OPT_UP_NODES
+     * bit 2 switches it off). */
+    std::vector<char> rebuild_n;
+    std::vector<int> rebuild_tab;
+    bool any_rebuild = false;
+    if (nodes4 && !(h->opt_up_nodes & 4)) {
+        if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
+        plk_up_rebuild_table(N, h->indptr.data(), h->indices.data(), h->node_has_data.data(), edge_tip.data(), node_int.data(),
+                             node_scale.data(), pair_of.data(), nin, rebuild_n, rebuild_tab);
+        for (int b = 0; b < N; b++) if (rebuild_n[b]) { skip_l[b] = 1; any_rebuild = true; }
+    }
     /* down-pass program: observation ops carry their staged code row and the (slot, row) of the next one */
     PlkChain ch2;
-    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch2, npairs4 ? skip_l.data() : nullptr);
+    plk_chain_build(N, h->pg, 1, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch2, npairs4 || any_rebuild ? skip_l.data() : nullptr);
     const int nobs2 = (int)h->obs_nodes.size();
     {
         const int D2 = h->slots_needed <= 4 ? 4 : (h->slots_needed <= 8 ? 8 : (h->slots_needed <= 16 ? 16 : INT_MAX));
@@ -2571,11 +2583,13 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
     if (nodes4) {
         if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
         plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                           node_int.data(), node_scale.data(), edge_mask, un4, npairs4 ? pair_of.data() : nullptr);
-        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc, npairs4, edge_tip.data());
+                           node_int.data(), node_scale.data(), edge_mask, un4, npairs4 ? pair_of.data() : nullptr,
+                           any_rebuild ? rebuild_n.data() : nullptr);
+        const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc, npairs4, edge_tip.data(),
+                                                   any_rebuild ? rebuild_tab.data() : nullptr, pair_of.data());
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
     }
-    const int *d_vis4 = nullptr, *d_ptabs = nullptr;
+    const int *d_vis4 = nullptr, *d_ptabs = nullptr, *d_rebuild = nullptr;
     double *d_tip4 = nullptr, *d_dtip4 = nullptr, *d_ptab4 = nullptr;
     size_t nptab = 0;
     auto cleanup = [&]() {};        /* everything below lives in grow-only engine buffers: no per-call hipMalloc / hipFree */
@@ -2594,6 +2608,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         const size_t o_em = edge_mask && E > 0 ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
         const size_t o_vis = nodes4 ? put(un4.rec.data(), un4.rec.size()) : 0;
         const size_t o_pt = npairs4 ? put(pair_tabs.data(), pair_tabs.size()) : 0;
+        const size_t o_rb = any_rebuild ? put(rebuild_tab.data(), rebuild_tab.size()) : 0;
         nptab = (size_t)C * npairs4 * h->nchar * h->nchar * 4;
         if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4))) return rc;
         if ((rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, ntab * (size_t)(1 + nM) + nptab))) return rc;
@@ -2607,6 +2622,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         d_nmask = node_mask ? b + o_nm : nullptr;
         d_vis4 = nodes4 ? b + o_vis : nullptr;
         d_ptabs = npairs4 ? b + o_pt : nullptr;
+        d_rebuild = any_rebuild ? b + o_rb : nullptr;
         d_tip4 = h->d_u4tip; d_dtip4 = h->d_u4tip + ntab; d_ptab4 = h->d_u4tip + ntab * (size_t)(1 + nM);
     }
     hipLaunchKernelGGL(k_build_tip, dim3(ntips + 1, C), dim3(64), 0, h->stream,
@@ -2656,7 +2672,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         a.MV = p; a.MVS = nullptr; a.wsite = nullptr;
         if (marg && msum_only) { a.MVS = p; a.wsite = h->d_w ? h->d_w + s0 : nullptr; p += (size_t)N * 4 * nwv; }
         else if (marg) p += (size_t)N * 4 * n;
-        a.visits = d_vis4; a.nvisits = un4.nvisits; a.ptab = npairs4 ? d_ptab4 : nullptr; a.npairs = npairs4;
+        a.visits = d_vis4; a.nvisits = un4.nvisits; a.ptab = npairs4 ? d_ptab4 : nullptr; a.npairs = npairs4; a.rebuild = d_rebuild;
         /* (the node-visit pass writes the row of every wanted edge: rows need clearing only under a mask) */
         if (deriv && E > 0 && !(nodes4 && !edge_mask)) HIPCHK(h, hipMemsetAsync(a.DV, 0, (size_t)ER * n * sizeof(double), h->stream));
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * 4 * nwv : (size_t)N * 4 * n) * sizeof(double), h->stream));

@@ -1159,20 +1159,53 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
  *                    storage index (internal child) or -1
  */
 enum { PLK_UN_OWN_D = 1, PLK_UN_FROM_REGS = 2 };                                              /* header flags */
-enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_PAIR = 8, PLK_UN_POS_SHIFT = 4 };   /* child flags;
+enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_PAIR = 8, PLK_UN_REBUILD = 16, PLK_UN_POS_SHIFT = 5 };   /* child flags;
    PLK_UN_PAIR: the child's message P_b L_b comes from pair table number `fifth field` (its two leaves' codes), L_b is not stored;
-   the record's fourth int then still holds the storage index (the child's own visit needs its G) */
+   the record's fourth int then still holds the storage index (the child's own visit needs its G);
+   PLK_UN_REBUILD: L_b is not stored either: b has two children, each a leaf or a pair node, and L_b is the product of their
+   two messages (tip-table row / pair-table row), listed in the rebuild table at 4 * storage index (plk_up_rebuild_table) */
 
 struct PlkUpNodes {
     std::vector<int> rec;
     int nvisits = 0;
 };
 
+/* Nodes whose L vector the k = 4 node-visit passes rebuild from tables instead of moving it through HBM: two children,
+ * each a leaf or a pair node, no data of its own, no rescaling at the node (with <= 6 edges below it, it never is one).
+ * rebuild[b] = 1 for them; table[4 * node_int[b]] = {t0, n0, t1, n1}: t >= 0 the tip slot of leaf child n, t <= -2 the pair
+ * table -2 - t of pair child n. */
+static inline void plk_up_rebuild_table(int N, const int *ip, const int *ix, const char *node_has_data, const int *edge_tip,
+                                        const int *node_int, const int *node_scale, const int *pair_of, int nint_nodes,
+                                        std::vector<char> &rebuild, std::vector<int> &table)
+{
+    rebuild.assign(N, 0);
+    table.assign(4 * (size_t)std::max(nint_nodes, 1), -1);
+    std::vector<int> edge_into(N, -1);
+    for (int a = 0; a < N; a++) for (int idx = ip[a]; idx < ip[a + 1]; idx++) edge_into[ix[idx]] = idx;
+    for (int b = 0; b < N; b++) {
+        const int e0 = ip[b];
+        if (ip[b + 1] - e0 != 2 || edge_into[b] < 0 || node_has_data[b] || node_scale[b] >= 0 || pair_of[b] >= 0 || node_int[b] < 0) continue;
+        int rec[4];
+        bool ok = true;
+        for (int j = 0; j < 2; j++) {
+            const int ch = ix[e0 + j];
+            if (edge_tip[e0 + j] >= 0) rec[2 * j] = edge_tip[e0 + j];
+            else if (pair_of[ch] >= 0) rec[2 * j] = -2 - pair_of[ch];
+            else ok = false;
+            rec[2 * j + 1] = ch;
+        }
+        if (!ok) continue;
+        rebuild[b] = 1;
+        for (int q = 0; q < 4; q++) table[4 * (size_t)node_int[b] + q] = rec[q];
+    }
+}
+
 /* pair_of: null, or N ints: index of the node's pair table (its message comes from the table, not from a stored L) or -1.
- * A pair child's flags carry PLK_UN_PAIR and its tip-slot field holds -2 - pair (tip slots are >= 0, -1 = internal). */
+ * A pair child's flags carry PLK_UN_PAIR and its tip-slot field holds -2 - pair (tip slots are >= 0, -1 = internal).
+ * rebuild: null, or N chars of plk_up_rebuild_table: such a child's flags carry PLK_UN_REBUILD. */
 static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
                                       const int *edge_tip, const int *node_int, const int *node_scale, const int *edge_mask,
-                                      PlkUpNodes &un, const int *pair_of = nullptr)
+                                      PlkUpNodes &un, const int *pair_of = nullptr, const char *rebuild = nullptr)
 {
     un.rec.clear(); un.nvisits = 0;
     std::vector<int> edge_into(N, -1);
@@ -1211,7 +1244,8 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
                     else if (sub[b]) fl = j == cont ? PLK_UN_CONTINUE : PLK_UN_STORE_G;
                 }
                 const bool pr = !leaf && pair_of && pair_of[b] >= 0;
-                const int cr[4] = {b, pr ? -2 - pair_of[b] : edge_tip[idx], fl | (pr ? PLK_UN_PAIR : 0) | (j << PLK_UN_POS_SHIFT), leaf ? -1 : node_int[b]};
+                const bool rbd = !leaf && !pr && rebuild && rebuild[b];
+                const int cr[4] = {b, pr ? -2 - pair_of[b] : edge_tip[idx], fl | (pr ? PLK_UN_PAIR : 0) | (rbd ? PLK_UN_REBUILD : 0) | (j << PLK_UN_POS_SHIFT), leaf ? -1 : node_int[b]};
                 un.rec.insert(un.rec.end(), cr, cr + 4);
             }
         un.nvisits++;
@@ -1224,7 +1258,8 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
 /* replays the kernel's walk: indices in range, every child position once, every G read after it was written (or
  * handed over in registers by the visit just before) */
 static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const int *ix, const PlkUpNodes &un, int nint_nodes, int ntips,
-                                             int nscale_slots, int npairs = 0, const int *edge_tip = nullptr)
+                                             int nscale_slots, int npairs = 0, const int *edge_tip = nullptr,
+                                             const int *rebuild_table = nullptr, const int *pair_of = nullptr)
 {
     std::vector<char> g_written(std::max(nint_nodes, 1), 0), visited(N, 0);
     size_t vp = 0;
@@ -1257,6 +1292,19 @@ static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const 
                 if (pi < 0 || pi >= npairs || b < 0 || b >= N || ip[b + 1] - ip[b] != 2) return plk_fmt("up nodes: bad pair child in visit %ld", v);
                 if (edge_tip && (edge_tip[ip[b]] < 0 || edge_tip[ip[b] + 1] < 0)) return plk_fmt("up nodes: pair child with an internal child in visit %ld", v);
                 t = -1;
+            }
+            if (fl & PLK_UN_REBUILD) {
+                /* L of this child is rebuilt from its table entry: two children, each the leaf / pair node the entry names,
+                 * tip slots and pair tables in range and the ones of those children */
+                if ((fl & PLK_UN_PAIR) || t != -1 || !rebuild_table || !edge_tip || !pair_of || bi < 0 || bi >= nint_nodes || b < 0 || b >= N || ip[b + 1] - ip[b] != 2)
+                    return plk_fmt("up nodes: bad rebuild child in visit %ld", v);
+                const int *rt = rebuild_table + 4 * (size_t)bi;
+                for (int q = 0; q < 2; q++) {
+                    const int cn = ix[ip[b] + q], ct = edge_tip[ip[b] + q];
+                    if (rt[2 * q + 1] != cn) return plk_fmt("up nodes: rebuild entry of visit %ld names the wrong child", v);
+                    if (ct >= 0 ? rt[2 * q] != ct : (pair_of[cn] < 0 || pair_of[cn] >= npairs || rt[2 * q] != -2 - pair_of[cn]))
+                        return plk_fmt("up nodes: rebuild entry of visit %ld names the wrong table", v);
+                }
             }
             if (b != ix[e0 + pos] || t < -1 || t >= ntips) return plk_fmt("up nodes: bad child in visit %ld", v);
             if (t < 0 && (bi < 0 || bi >= nint_nodes)) return plk_fmt("up nodes: bad storage index in visit %ld", v);

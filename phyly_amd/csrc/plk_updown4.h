@@ -53,6 +53,7 @@ struct Up4Args {
                                       two-leaf node, by the combined code of its leaves (k_build_tables_pt); null = none */
     int npairs;
     int nvisits;
+    const int *rebuild;            /* k_up4_nodes: table of plk_up_rebuild_table() (children whose L is a product of two table rows) */
 };
 
 struct v4 { double a, b, c, d; };
@@ -647,6 +648,23 @@ __device__ static inline v4 u4n_pair_message(const Up4Args &a, int c, int pair, 
     return ld4u(a.ptab + ((size_t)c * a.npairs + pair) * a.nchar * a.nchar * 4, 4u * comb);
 }
 
+/* L_b of internal child b (record flags fl, storage index bi): read from LN, or -- PLK_UN_REBUILD: both of b's children are
+ * leaves or pair nodes -- the product of their two messages, each one row of a tip table or of a pair table (64 bytes of
+ * L2-resident tables instead of 32 bytes written by the down pass and read here, per category) */
+__device__ static inline v4 u4n_child_L(const Up4Args &a, int c, int fl, int bi, size_t tabc, unsigned us, unsigned us4, size_t n)
+{
+    if (!(fl & PLK_UN_REBUILD)) return ld4u(a.LN + ((size_t)bi * a.C + c) * n * 4, us4);
+    const PLK_AS4 int *rt = as_uniform(a.rebuild) + 4 * bi;
+    v4 m[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int t = rt[2 * q], nd = rt[2 * q + 1];
+        if (t >= 0) m[q] = ld4u(a.tip + (size_t)c * tabc + (size_t)t * a.nchar * 4, 4u * at_u(a.codes + (size_t)nd * a.Spad + a.s0, us));
+        else m[q] = u4n_pair_message(a, c, -2 - t, nd, us);
+    }
+    return v4{m[0].a * m[1].a, m[0].b * m[1].b, m[0].c * m[1].c, m[0].d * m[1].d};
+}
+
 template <int CM>
 __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up4_nodes(Up4Args a)
 {
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
         do { const int b_ = ch[4 * (J)], t_ = ch[4 * (J) + 1], pos_ = ch[4 * (J) + 2] >> PLK_UN_POS_SHIFT; \
              if (t_ >= 0) M = ld4u(a.tip + (size_t)(C_) * tabc + (size_t)t_ * a.nchar * 4, 4u * at_u(a.codes + (size_t)b_ * a.Spad + a.s0, us)); \
              else if (t_ < -1) M = u4n_pair_message(a, C_, -2 - t_, b_, us);                              \
-             else { const v4 x_ = ld4u(a.LN + ((size_t)ch[4 * (J) + 3] * a.C + (C_)) * n * 4, us4);        \
+             else { const v4 x_ = u4n_child_L(a, C_, ch[4 * (J) + 2], ch[4 * (J) + 3], tabc, us, us4, n);   \
                     M = mv4(Pm + ((size_t)(C_) * a.E + e0 + pos_) * 16, x_);                              \
                     if (const4(x_)) M = x_; } } while (0)
         if (deg <= 2) {
@@ -700,7 +718,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (ch[1] >= 0) m0 = ld4u(tipc + (size_t)ch[1] * a.nchar * 4, cd0);
                 else if (ch[1] < -1) m0 = u4n_pair_message(a, c, -2 - ch[1], ch[0], us);
                 else {
-                    const v4 x = ld4u(a.LN + ((size_t)ch[3] * a.C + c) * n * 4, us4);
+                    const v4 x = u4n_child_L(a, c, fl0, ch[3], tabc, us, us4, n);
                     m0 = mv4(Pm + ((size_t)c * a.E + e0 + (fl0 >> PLK_UN_POS_SHIFT)) * 16, x);
                     if (const4(x)) m0 = x;
                 }
@@ -708,7 +726,7 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (ch[5] >= 0) m1 = ld4u(tipc + (size_t)ch[5] * a.nchar * 4, cd1);
                     else if (ch[5] < -1) m1 = u4n_pair_message(a, c, -2 - ch[5], ch[4], us);
                     else {
-                        const v4 x = ld4u(a.LN + ((size_t)ch[7] * a.C + c) * n * 4, us4);
+                        const v4 x = u4n_child_L(a, c, fl1, ch[7], tabc, us, us4, n);
                         m1 = mv4(Pm + ((size_t)c * a.E + e0 + (fl1 >> PLK_UN_POS_SHIFT)) * 16, x);
                         if (const4(x)) m1 = x;
                     }

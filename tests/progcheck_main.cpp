@@ -138,6 +138,45 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
             }
         }
     }
+    /* the k = 4 node visits with pair tables and table-rebuilt children (run_updown4): pair nodes as the engine picks them,
+     * rebuild table, records, and a negative control (an entry that names the wrong table must be refused) */
+    if (E > 0) {
+        std::vector<int> pair_of(N, -1), edge_into(N, -1);
+        for (int a = 0; a < N; a++) for (int idx = t.ip[a]; idx < t.ip[a + 1]; idx++) edge_into[t.ix[idx]] = idx;
+        int npairs = 0;
+        for (int b = 0; b < N; b++) {
+            const int e0 = t.ip[b];
+            if (t.ip[b + 1] - e0 != 2 || edge_into[b] < 0 || has[b]) continue;
+            if (edge_tip[e0] < 0 || edge_tip[e0 + 1] < 0) continue;
+            pair_of[b] = npairs++;
+        }
+        std::vector<char> rb;
+        std::vector<int> rtab;
+        plk_up_rebuild_table(N, t.ip.data(), t.ix.data(), has.data(), edge_tip.data(), node_int.data(), node_scale.data(), pair_of.data(), nin, rb, rtab);
+        PlkUpNodes un;
+        plk_up_nodes_build(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), edge_tip.data(), node_int.data(), node_scale.data(), nullptr, un,
+                           pair_of.data(), rb.data());
+        bad = plk_up_nodes_check(N, E, t.ip.data(), t.ix.data(), un, nin, ntips, nsc, npairs, edge_tip.data(), rtab.data(), pair_of.data());
+        if (!bad.empty()) return "up nodes (pairs, rebuilt children): " + bad;
+        int nflag = 0, nrb = 0;
+        size_t vp = 0;
+        for (int v = 0; v < un.nvisits; v++) {
+            const int *h = &un.rec[vp];
+            for (int j = 0; j < h[1]; j++) if (h[8 + 4 * j + 2] & PLK_UN_REBUILD) nflag++;
+            vp += 8 + 4 * (size_t)h[1];
+        }
+        for (int b = 0; b < N; b++) if (rb[b]) {
+            nrb++;
+            if (pair_of[b] >= 0 || has[b] || t.ip[b + 1] - t.ip[b] != 2) return "rebuild table: node " + std::to_string(b) + " does not qualify";
+        }
+        if (nflag != nrb) return "up nodes: " + std::to_string(nrb) + " rebuilt nodes, " + std::to_string(nflag) + " flagged child records";
+        if (nrb > 0) {
+            std::vector<int> r2 = rtab;
+            for (int b = 0; b < N; b++) if (rb[b]) { r2[4 * (size_t)node_int[b]] += r2[4 * (size_t)node_int[b]] >= 0 ? 1 : -1; break; }
+            if (plk_up_nodes_check(N, E, t.ip.data(), t.ix.data(), un, nin, ntips, nsc, npairs, edge_tip.data(), r2.data(), pair_of.data()).empty())
+                return "negative control: rebuild entry with the wrong table accepted";
+        }
+    }
     if (pg.slots_needed > PLK_FUSED_SLOTS) return "";
     PlkFused fu;
     plk_fused_build(N, pg, fu);
