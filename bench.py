@@ -50,7 +50,7 @@ KERNEL_SOURCES = {
     "k_ll_vec": ["plk_vec.h", "plk_vec_matvec_asm.h", "plk_program.h"],
     "k_ll_mfma": ["plk_mfma.h"],
     "k_ll_generic": ["plk_engine.hip"],
-    "deriv4": ["plk_updown4.h", "plk_down4_asm.h"],
+    "deriv4": ["plk_updown4.h", "plk_down4_asm.h", "plk_program.h"],
     "deriv_vec": ["plk_updown_vec.h", "plk_vec_matvec_asm.h"],
     "deriv_mfma": ["plk_mfma_updown.h"],
 }
