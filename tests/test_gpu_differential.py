@@ -178,7 +178,7 @@ def test_random_inputs_match_oracle(oracle, kind):
     orc = {"ll": oracle.arbplf_ll, "deriv": oracle.arbplf_deriv, "marginal": oracle.arbplf_marginal}[kind]
     rng = random.Random({"ll": 11, "deriv": 22, "marginal": 33}[kind])
     done = skipped = 0
-    for case in range(55):
+    for case in range(46):
         x = random_model(rng, kind)
         s = json.dumps(x)
         want = json.loads(orc(s))
@@ -192,7 +192,7 @@ def test_random_inputs_match_oracle(oracle, kind):
         got = json.loads(prod(s))
         _check(kind, got, want)
         done += 1
-    assert done >= 30, (done, skipped)
+    assert done >= 25, (done, skipped)
 
 
 @pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 25, 32, 33, 48, 64])

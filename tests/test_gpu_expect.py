@@ -263,7 +263,7 @@ def _random_query(rng, kind):
 def test_random_inputs_match_oracle(oracle, kind):
     rng = random.Random({"dwell": 44, "trans": 55, "em_update": 66}[kind])
     done = 0
-    ncases = {"dwell": 24, "trans": 20, "em_update": 24}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
+    ncases = {"dwell": 20, "trans": 16, "em_update": 20}[kind]      # trans: one binary128 Frechet build per state pair in the oracle
     for case in range(ncases):
         x = _random_query(rng, kind)
         s = json.dumps(x)
