@@ -82,6 +82,7 @@ struct plk_engine {
     uint8_t *d_codes = nullptr;          /* [N][Spad] */
     int nchar = 0;
     std::vector<double> defs;            /* [nchar][k] host */
+    std::vector<char> node_observed;     /* N: every site's code at the node is a single observed state (definition = one 1.0) */
     double *d_defs = nullptr;            /* [nchar][K] zero padded */
     double *d_B = nullptr;               /* [N][k][S] */
     std::vector<char> node_has_data;     /* internal nodes whose observations are not all-ones */
@@ -670,7 +671,8 @@ __global__ void k_build_tables_pt(int E, int ntab, int units, int nchar, const i
 }
 
 /* flags[n] bit 0: some site's code at node n is not an all-ones definition; bit 1: some code is >= nchar
- * (the kernels index LDS and the tip tables with the codes: an out-of-range code must never reach them) */
+ * (the kernels index LDS and the tip tables with the codes: an out-of-range code must never reach them); bit 2: some
+ * code's definition is not a single 1.0 among zeros (code_trivial[ch]: bit 0 all-ones definition, bit 1 single state) */
 __global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ codes, int nchar,
                              const int *__restrict__ code_trivial, int *__restrict__ flags)
 {
@@ -687,10 +689,10 @@ __global__ void k_node_flags(long S, long Spad, const uint8_t *__restrict__ code
         for (int j = 0; j < 16; j++) {
             const long s = v * 16 + j;
             const int ch = (wds[j >> 2] >> ((j & 3) * 8)) & 0xff;
-            if (s < S) bad |= ch >= nchar ? 2 : !code_trivial[ch];
+            if (s < S) { const int ct = ch >= nchar ? 0 : code_trivial[ch]; bad |= ch >= nchar ? 2 : ((ct & 1) ? 0 : 1) | ((ct & 2) ? 0 : 4); }
         }
     }
-    const int wbad = (__any(bad & 1) ? 1 : 0) | (__any(bad & 2) ? 2 : 0);
+    const int wbad = (__any(bad & 1) ? 1 : 0) | (__any(bad & 2) ? 2 : 0) | (__any(bad & 4) ? 4 : 0);
     if (wbad && (threadIdx.x & 63) == 0) atomicOr(&flags[n], wbad);
 }
 
@@ -1620,12 +1622,18 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
                           where == PLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     h->defs.assign(defs, defs + (size_t)nchar * k);
     std::vector<double> dpad((size_t)nchar * K, 0.0);
-    std::vector<int> trivial(nchar, 1);
-    for (int ch = 0; ch < nchar; ch++)
+    std::vector<int> trivial(nchar, 1);                 /* bit 0: all-ones definition; bit 1: a single 1.0 among zeros */
+    for (int ch = 0; ch < nchar; ch++) {
+        int nnz = 0, ones = 0;
         for (int j = 0; j < k; j++) {
-            dpad[(size_t)ch * K + j] = defs[(size_t)ch * k + j];
-            if (defs[(size_t)ch * k + j] != 1.0) trivial[ch] = 0;
+            const double d = defs[(size_t)ch * k + j];
+            dpad[(size_t)ch * K + j] = d;
+            if (d != 1.0) trivial[ch] = 0;
+            if (d != 0.0) nnz++;
+            if (d == 1.0) ones++;
         }
+        if (nnz == 1 && ones == 1) trivial[ch] |= 2;
+    }
     if ((rc = dev_upload(h, &h->d_defs, dpad.data(), dpad.size()))) return rc;
     h->S = S; h->Spad = Spad; h->nchar = nchar; h->pat_mode = 1;
     if (h->d_B) { (void)hipFree(h->d_B); h->d_B = nullptr; }
@@ -1643,13 +1651,15 @@ extern "C" int plk_set_patterns_codes(plk_engine *h, long S, const uint8_t *code
     HIPCHK(h, hipMemcpy(flags.data(), d_flags, N * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(d_triv); (void)hipFree(d_flags);
     h->node_has_data.assign(N, 0);
+    h->node_observed.assign(N, 0);
     for (int a = 0; a < N; a++) {
         if (flags[a] & 2) {
             h->pat_mode = 0;
             h->err = "plk_set_patterns_codes: a pattern code is not less than the number of character definitions";
             return PLK_E_ARG;
         }
-        h->node_has_data[a] = flags[a] ? 1 : 0;
+        h->node_has_data[a] = (flags[a] & 3) ? 1 : 0;
+        h->node_observed[a] = (flags[a] & 4) ? 0 : 1;
     }
     h->prog_dirty = true;
     return PLK_OK;
@@ -1669,6 +1679,7 @@ extern "C" int plk_set_patterns_dense(plk_engine *h, long S, const double *B, in
     if (h->d_w) { (void)hipFree(h->d_w); h->d_w = nullptr; }
     h->S = S; h->Spad = S; h->pat_mode = 2; h->nchar = 0;
     h->node_has_data.assign(h->N, 1);
+    h->node_observed.clear();
     h->prog_dirty = true;
     return PLK_OK;
 }
@@ -2747,12 +2758,13 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     /* nodes finished inside their parent's visit (no marginals asked for): the up pass rebuilds their L vector from the
      * tip tables, so the down pass does not store it (a third of the stored vectors at BASELINE config 4) */
     std::vector<char> skip_l(N, 0);
-    for (int u = 1; u < N; u++) { const int b = h->preorder[u]; skip_l[b] = plk_up_inlinable(h->indptr.data(), edge_tip.data(), b, marg); }
+    const char *leaf_obs = h->node_observed.size() == (size_t)N ? h->node_observed.data() : nullptr;
+    for (int u = 1; u < N; u++) { const int b = h->preorder[u]; skip_l[b] = plk_up_inlinable(h->indptr.data(), edge_tip.data(), b, marg, h->indices.data(), leaf_obs); }
     PlkChain ch;
     plk_chain_build(N, h->pg, 3, h->indices.data(), node_int.data(), nullptr, node_scale.data(), ch, skip_l.data());
     PlkUpVisits uv;
     plk_up_visits_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
-                        node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv);
+                        node_int.data(), node_scale.data(), deriv, marg, edge_mask, node_mask, uv, leaf_obs);
     {
         std::string bad = plk_chain_check(N, h->pg, ch, 3, INT_MAX, nin, nie, nsc, 0, 0);
         if (bad.empty()) bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, deriv);
@@ -2770,6 +2782,15 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
     const size_t o_vis = put(uv.rec.data(), uv.rec.size());
     const size_t o_kind = put(uv.kind.data(), uv.kind.size()), o_edge = put(uv.edge.data(), uv.edge.size());
     const size_t o_te = put(te.data(), te.size());
+    /* the state a character code observes: its definition row is one 1.0 among zeros (leaf marginals of such codes are one
+     * dot product in the up pass instead of a matrix-vector product) */
+    std::vector<int> code_state((size_t)std::max(h->nchar, 1), -1);
+    for (int cd = 0; cd < h->nchar && h->defs.size() == (size_t)h->nchar * k; cd++) {
+        int nnz = 0, at = -1;
+        for (int j = 0; j < k; j++) if (h->defs[(size_t)cd * k + j] != 0.0) { nnz++; at = j; }
+        if (nnz == 1 && h->defs[(size_t)cd * k + at] == 1.0) code_state[cd] = at;
+    }
+    const size_t o_cs = put(code_state.data(), code_state.size());
     const size_t ntab = (size_t)C * (ntips + 1) * h->nchar * K;
     const size_t nmat = (size_t)C * E * K * K + (size_t)C * (nstream + 3) * K * K;
     if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4)) ||
@@ -2814,6 +2835,7 @@ static int run_updown_vec(plk_engine *h, bool deriv, bool marg, const int *edge_
         a.PT = d_PT; a.tip = d_tipv; a.dtip = d_dtipv; a.codes = h->d_codes; a.cat_prior = h->d_cat_prior; a.root_w = h->d_root_w;
         a.visits = b + o_vis; a.nvisits = uv.nvisits; a.MS = d_MS; a.nstream = nstream;
         a.reg_lo = vec_reg_window(h);
+        a.code_state = b + o_cs;
         double *p = h->d_work;
         a.LN = p; p += (size_t)nin * C * K * n;
         a.FN = p; p += (size_t)nin * C * K * n;

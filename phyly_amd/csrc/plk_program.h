@@ -1008,17 +1008,25 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
  * asked for (PLK_UP_INLINE): its forward vector is used while it is in registers and never stored, the node gets no
  * visit of its own, and the child's fourth int is the offset (in rec) of a 12-int record placed after all visits:
  *   node, has_data, rescaling slot or -1, number of leaves (1 or 2), first CSR edge,
- *   leaf 0: node, tip slot, derivative wanted;  leaf 1: node, tip slot, derivative wanted;  0
+ *   leaf 0: node, tip slot, wanted (bit 0 derivative, bit 1 marginal);  leaf 1: node, tip slot, wanted;  0
+ * With marginals a child is inlined only if all its leaves observe single states at every site (leaf_observed).
  */
 enum { PLK_UP_WANT_D = 1, PLK_UP_WANT_F = 2, PLK_UP_WANT_M = 4, PLK_UP_STORE_F = 8, PLK_UP_INLINE = 16 };
 
 /* a node whose one or two children are all leaves is finished inside its parent's visit when no marginals are asked for:
  * its forward vector is never stored, and neither is its L vector (the up pass rebuilds it from the tip tables) */
-static inline bool plk_up_inlinable(const int *ip, const int *edge_tip, int b, bool marg)
+static inline bool plk_up_inlinable(const int *ip, const int *edge_tip, int b, bool marg, const int *ix = nullptr,
+                                    const char *leaf_observed = nullptr)
 {
     const int d = ip[b + 1] - ip[b];
-    if (marg || d < 1 || d > 2) return false;
-    for (int idx = ip[b]; idx < ip[b + 1]; idx++) if (edge_tip[idx] < 0) return false;
+    if (d < 1 || d > 2) return false;
+    /* with marginals: only when every site of every leaf below observes a single state (leaf_observed, from the pattern
+     * upload) -- the leaf's marginal is then one dot product per site, done in the parent's parent's visit too */
+    if (marg && (!ix || !leaf_observed)) return false;
+    for (int idx = ip[b]; idx < ip[b + 1]; idx++) {
+        if (edge_tip[idx] < 0) return false;
+        if (marg && !leaf_observed[ix[idx]]) return false;
+    }
     return true;
 }
 
@@ -1031,7 +1039,7 @@ struct PlkUpVisits {
 
 static inline void plk_up_visits_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
                                        const int *edge_tip, const int *node_int, const int *node_scale, bool deriv, bool marg,
-                                       const int *edge_mask, const int *node_mask, PlkUpVisits &uv)
+                                       const int *edge_mask, const int *node_mask, PlkUpVisits &uv, const char *leaf_observed = nullptr)
 {
     uv.rec.clear(); uv.kind.clear(); uv.edge.clear(); uv.nvisits = 0;
     auto flags = [&](int idx, int b) {
@@ -1042,7 +1050,7 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
         return (wd ? PLK_UP_WANT_D : 0) | (wf ? PLK_UP_WANT_F : 0) | (wm ? PLK_UP_WANT_M : 0) | (!leaf ? PLK_UP_STORE_F : 0);
     };
     auto put = [&](int kind, int edge) { uv.kind.push_back(kind); uv.edge.push_back(edge); };
-    auto inlinable = [&](int b) { return plk_up_inlinable(ip, edge_tip, b, marg); };
+    auto inlinable = [&](int b) { return plk_up_inlinable(ip, edge_tip, b, marg, ix, leaf_observed); };
     std::vector<int> inl;                /* inline records, appended after the visits */
     std::vector<size_t> fix;             /* positions in rec that hold an offset into inl */
     for (int u = 0; u < N; u++) {
@@ -1064,7 +1072,7 @@ static inline void plk_up_visits_build(int N, const int *ip, const int *ix, cons
                 for (int q = 0; q < db; q++) {
                     r[5 + 3 * q] = ix[s0 + q];
                     r[6 + 3 * q] = edge_tip[s0 + q];
-                    r[7 + 3 * q] = deriv && (!edge_mask || edge_mask[s0 + q]) ? 1 : 0;
+                    r[7 + 3 * q] = (deriv && (!edge_mask || edge_mask[s0 + q]) ? 1 : 0) | (marg && (!node_mask || node_mask[ix[s0 + q]]) ? 2 : 0);
                 }
                 second = (int)inl.size();            /* becomes -2 - (visit_ints + offset) below */
                 fix.push_back(uv.rec.size() + 1);

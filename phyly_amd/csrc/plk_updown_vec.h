@@ -55,6 +55,7 @@ struct UpVecArgs {
     double *LH, *DV, *MV;          /* [n], [E][n], [N][k][n] */
     double *MVS;                   /* site-summed marginals only: [(node * k + state)][nwaves] per-wave weighted sums, MV unused */
     const double *wsite;           /* [n] site weights of the chunk or null */
+    const int *code_state;         /* [nchar]: the state a character code observes (definition row = one 1.0, zeros elsewhere), or -1 */
 };
 
 /* child record of a visit: 4 ints */
@@ -334,6 +335,19 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                  double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
                  const double t_ = pc * FB[i] * LB[i]; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
 
+            /* marginal of a leaf that observes state ST_ at this site: one non-zero entry FS_ = F(ST_) (B = 1 there) */
+#define UDV_OUT_M1(NODE, ST_, FS_)                                                                        \
+            do { if (a.MVS) {                                                                             \
+                     const double v_ = (valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv * pc : 0.0) * (FS_);  \
+                     _Pragma("unroll") for (int i = 0; i < K; i++) {                                      \
+                         const double t_ = wave64_sum_lane63((ST_) == i ? v_ : 0.0);                      \
+                         if (i < a.k && (threadIdx.x & 63) == 63) {                                       \
+                             double *mp_ = a.MVS + ((size_t)(NODE) * a.k + i) * nwv + wv;                 \
+                             *mp_ = first_cat ? t_ : *mp_ + t_; } }                                       \
+                 } else if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {         \
+                 double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
+                 const double t_ = (ST_) == i ? pc * (FS_) : 0.0; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
+
             /* one edge at a time; the messages of the siblings are recomputed for every edge (a binary node costs three
              * products per internal edge either way; handling both children in one visit would keep F_a, both child
              * messages and both edge-form vectors live -- 300 registers at K = 20, one wave per SIMD, measured 9 M
@@ -395,7 +409,25 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     for (int i = 0; i < K; i++) d = fma(fe[i], y[i], d);
                     UDV_OUT_D(e0 + j, pc * d);
                 }
-                if (fl & UDV_WANT_F) {
+                /* Marginal of a leaf whose whole wave observes single states: F_b o B_b has one non-zero entry, at the observed
+                 * state s -- F_b(s) = sum_j P[j][s] fe[j], a K-term dot product with row s of the transposed matrix (gathered
+                 * per lane, L2 resident) in the order the full product sums it (same bits), instead of the K x K product.
+                 * The matrix of the stream is skipped, not consumed (its successor is still requested ahead). */
+                bool leaf_done = false;
+                if (MARG && t >= 0 && (fl & UDV_WANT_F) && (fl & UDV_WANT_M)) {
+                    const int st = a.code_state[a.codes[(size_t)b * a.Spad + sg]];
+                    if (__all(st >= 0)) {
+                        leaf_done = true;
+                        vec_touch<K>(ms + 2 * KK);
+                        ms += KK;
+                        const double *col = a.PT + ((size_t)c * a.E + e0 + j) * KK + (size_t)st * K;
+                        double fs = col[0] * fe[0];
+#pragma unroll
+                        for (int i = 1; i < K; i++) fs = fma(col[i], fe[i], fs);
+                        UDV_OUT_M1(b, st, fs);
+                    }
+                }
+                if ((fl & UDV_WANT_F) && !leaf_done) {
                     double fb[K];
                     vec_touch<K>(ms + 2 * KK);
                     vec_matvec<K>(ms, fe, fb);
@@ -404,10 +436,10 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (MARG && (fl & UDV_WANT_M)) {
                         double lb[K];
                         if (t >= 0) udv_gather<K>(tipc + ((size_t)a.ntips * a.nchar + a.codes[(size_t)b * a.Spad + sg]) * K, lb);
-                        else udv_load<K>(a.LN + ((size_t)bi * a.C + c) * K * n, n, slc, lb);
+                        else UDV_CHILD_L(b, t, bi, lb);          /* stored, or rebuilt from the tip tables (inline child) */
                         UDV_OUT_M(b, fb, lb);
                     }
-                    if (DERIV && (fl & PLK_UP_INLINE)) {
+                    if ((DERIV || MARG) && (fl & PLK_UP_INLINE)) {
                         /* the child's own children are leaves: their edge forms are finished here, while the child's
                          * forward vector is in registers (it is never stored, the child has no visit of its own) */
                         const PLK_AS4 int *q = vis + (-2 - t);       /* the child's inline record (plk_program.h) */
@@ -425,7 +457,39 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                         const int nl = q[3], le0 = q[4];
                         const int cd0 = a.codes[(size_t)q[5] * a.Spad + sg];
                         const int cd1 = nl == 2 ? a.codes[(size_t)q[8] * a.Spad + sg] : 0;
-                        if (q[7]) {
+                        if (MARG) {
+                            /* marginals of the child's leaves (each observes one state at every site: the builder inlined the
+                             * child on that condition): F_leaf(s) = sum_j P_leaf[j][s] (F_b o message of the other leaf)[j] */
+                            const int st0 = a.code_state[cd0], st1 = nl == 2 ? a.code_state[cd1] : 0;
+                            if (q[7] & 2) {
+                                double g[K];
+#pragma unroll
+                                for (int i = 0; i < K; i++) g[i] = fb[i];
+                                if (nl == 2) {
+                                    double m[K];
+                                    udv_gather<K>(tipc + ((size_t)q[9] * a.nchar + cd1) * K, m);
+#pragma unroll
+                                    for (int i = 0; i < K; i++) g[i] *= m[i];
+                                }
+                                const double *col = a.PT + ((size_t)c * a.E + le0) * KK + (size_t)(st0 < 0 ? 0 : st0) * K;
+                                double fs = col[0] * g[0];
+#pragma unroll
+                                for (int i = 1; i < K; i++) fs = fma(col[i], g[i], fs);
+                                UDV_OUT_M1(q[5], st0, fs);
+                            }
+                            if (nl == 2 && (q[10] & 2)) {
+                                double g[K], m[K];
+                                udv_gather<K>(tipc + ((size_t)q[6] * a.nchar + cd0) * K, m);
+#pragma unroll
+                                for (int i = 0; i < K; i++) g[i] = fb[i] * m[i];
+                                const double *col = a.PT + ((size_t)c * a.E + le0 + 1) * KK + (size_t)(st1 < 0 ? 0 : st1) * K;
+                                double fs = col[0] * g[0];
+#pragma unroll
+                                for (int i = 1; i < K; i++) fs = fma(col[i], g[i], fs);
+                                UDV_OUT_M1(q[8], st1, fs);
+                            }
+                        }
+                        if (DERIV && (q[7] & 1)) {
                             double y[K], d = 0.0;
                             udv_gather<K>(dtipc + ((size_t)q[6] * a.nchar + cd0) * K, y);
                             if (nl == 2) {
@@ -438,7 +502,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                             for (int i = 0; i < K; i++) d = fma(fb[i], y[i], d);
                             UDV_OUT_D(le0, pc * d);
                         }
-                        if (nl == 2 && q[10]) {
+                        if (DERIV && nl == 2 && (q[10] & 1)) {
                             double y[K], m[K], d = 0.0;
                             udv_gather<K>(dtipc + ((size_t)q[9] * a.nchar + cd1) * K, y);
                             udv_gather<K>(tipc + ((size_t)q[6] * a.nchar + cd0) * K, m);
@@ -452,6 +516,7 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
 #undef UDV_OUT_D
 #undef UDV_OUT_M
+#undef UDV_OUT_M1
 #undef UDV_CHILD_L
     }
 }

@@ -89,14 +89,43 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
         for (int e = 0; e < E; e++) { lcg = lcg * 1664525u + 1013904223u; emask[e] = (lcg >> 24) % 3 != 0; }
         for (int a = 0; a < N; a++) { lcg = lcg * 1664525u + 1013904223u; nmask[a] = (lcg >> 24) % 3 != 0; }
         const int modes[3][2] = {{1, 0}, {0, 1}, {1, 1}};
+        /* observed[a]: every site of leaf a is a single state (marginal queries then inline pre-terminal nodes too): none, a
+         * pseudo-random half, all */
+        std::vector<char> observed(N, 0);
         for (int md = 0; md < 3; md++)
-            for (int masked = 0; masked < 2; masked++) {
+            for (int masked = 0; masked < 2; masked++)
+            for (int ob = 0; ob < (modes[md][1] ? 3 : 1); ob++) {
+                for (int a = 0; a < N; a++) { lcg = lcg * 1664525u + 1013904223u; observed[a] = ob == 2 || (ob == 1 && (lcg >> 24) % 2); }
                 PlkUpVisits uv;
                 plk_up_visits_build(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), edge_tip.data(), node_int.data(),
                                     node_scale.data(), modes[md][0] != 0, modes[md][1] != 0, masked ? emask.data() : nullptr,
-                                    masked ? nmask.data() : nullptr, uv);
+                                    masked ? nmask.data() : nullptr, uv, ob ? observed.data() : nullptr);
                 bad = plk_up_visits_check(N, E, uv, nin, ntips, nsc, modes[md][0] != 0);
                 if (!bad.empty()) return "up visits (deriv " + std::to_string(modes[md][0]) + ", marg " + std::to_string(modes[md][1]) + "): " + bad;
+                if (modes[md][1]) {
+                    /* every wanted marginal is produced exactly once: by a visit's child record, by the root's header, or by
+                     * an inline record's leaf entry; an inlined node's leaves are all observed */
+                    std::vector<int> mdone(N, 0);
+                    size_t vp = 0;
+                    for (int v = 0; v < uv.nvisits; v++) {
+                        const int *h = &uv.rec[vp];
+                        if (h[6]) mdone[h[0]]++;
+                        for (int j = 0; j < h[1]; j++) {
+                            const int *c = h + 8 + 4 * j;
+                            if (c[2] & PLK_UP_WANT_M) mdone[c[0]]++;
+                            if (c[2] & PLK_UP_INLINE) {
+                                const int *q = &uv.rec[-2 - c[1]];
+                                for (int l = 0; l < q[3]; l++) {
+                                    if (q[7 + 3 * l] & 2) mdone[q[5 + 3 * l]]++;
+                                    if (!ob || !observed[q[5 + 3 * l]]) return "up visits: a node with an unobserved leaf is inlined in a marginal pass";
+                                }
+                            }
+                        }
+                        vp += 8 + 4 * (size_t)h[1];
+                    }
+                    for (int a = 0; a < N; a++)
+                        if (mdone[a] != ((!masked || nmask[a]) ? 1 : 0)) return "up visits: marginal of node " + std::to_string(a) + " produced " + std::to_string(mdone[a]) + " times";
+                }
                 if (md == 0 && !masked && !uv.kind.empty()) {      /* negative control: a dropped matrix must be noticed */
                     PlkUpVisits u2 = uv;
                     u2.kind.pop_back(); u2.edge.pop_back();
