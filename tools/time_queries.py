@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Whole-step wall time of plk_deriv and plk_marginal (site-summed outputs, patterns resident) on a BASELINE config:
   python tools/time_queries.py --config 4 --sites 1000000
-prints one JSON line.  bench.py times ll and deriv; this adds the marginal query for DESIGN.md's table."""
+prints one JSON line.  bench.py times ll and deriv; this adds the marginal query (and, with --hess-sites, the Hessian) for
+DESIGN.md's table."""
 import argparse
 import json
 import os
@@ -17,6 +18,7 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--sites", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--hess-sites", type=int, default=0, help="also time plk_hess (E + 1 second-order passes) on this many sites")
     a = ap.parse_args()
     wl = synth.Workload(a.config)
     S = a.sites or min(wl.default_S, 2_000_000)
@@ -31,6 +33,13 @@ def main():
             fn()
         dt = (time.perf_counter() - t0) / a.reps
         out[name] = {"ms_per_step": dt * 1e3, "sites_per_s": S / dt}
+    if a.hess_sites:
+        eng.set_patterns_codes(wl.simulate(a.hess_sites), wl.defs)
+        eng.hess()
+        t0 = time.perf_counter()
+        eng.hess()
+        dt = time.perf_counter() - t0
+        out["hess"] = {"sites": a.hess_sites, "edges": wl.E, "ms": dt * 1e3, "site_passes_per_s": a.hess_sites * (wl.E + 1) / dt}
     print(json.dumps(out))
     eng.close()
 
