@@ -1,4 +1,4 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_deriv_marginal.py tests/test_gpu_differential.py -x -q 2>&1 | tail -4 || exit 1
-python3 tools/time_queries.py --config 4 2>/dev/null | grep '^{' > gpurun_out/q4.json || exit 1
-cat gpurun_out/q4.json
+root=$(pwd)
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/hess_stats -o run -- python3 $root/tools/time_queries.py --config 3 --sites 100000 --hess-sites 50000 > $root/gpurun_out/hess_prof.log 2>&1
+cd $root; find gpurun_out/hess_stats -name '*kernel_trace.csv' -delete; tail -2 gpurun_out/hess_prof.log

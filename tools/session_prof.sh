@@ -12,4 +12,4 @@ root=$(pwd)
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/r03/em5_stats -o run -- python3 $root/tools/profile_ll.py --config 5 --sites 100000 --what em > $root/gpurun_out/r03/em5.log 2>&1) || exit 1
 find gpurun_out/r03/em5_stats -name '*kernel_trace.csv' -delete 2>/dev/null
 : > gpurun_out/r03/query_times.jsonl
-for c in 2 3 4 5; do hs=0; [ $c = 2 ] && hs=100000; [ $c = 3 ] && hs=50000; python3 tools/time_queries.py --config $c --hess-sites $hs 2>/dev/null | grep '^{' >> gpurun_out/r03/query_times.jsonl || exit 1; done
+for c in 2 3 4 5; do hs=0; [ $c = 2 ] && hs=1000000; [ $c = 3 ] && hs=500000; python3 tools/time_queries.py --config $c --hess-sites $hs 2>/dev/null | grep '^{' >> gpurun_out/r03/query_times.jsonl || exit 1; done
