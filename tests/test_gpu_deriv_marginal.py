@@ -264,3 +264,23 @@ def test_k4_node_visit_up_pass_equals_edge_up_pass(eng, oracle, cfg):
     m, ow = oracle_model(oracle, w, codes[:, :60])
     want = oracle.site_deriv(m, ow, _dense_from_codes(w, codes[:, :60]), precise=2)
     assert _row_err(out[2][0][:60], want) <= 1e-12
+
+
+@pytest.mark.parametrize("cfg,S", [(3, 300), (4, 64), (5, 32)])
+def test_derivative_after_an_ll_evaluation_at_new_rates(eng, cfg, S):
+    """an ll evaluation runs K1 without dP = r Q P (nothing in it reads dP); the first derivative query afterwards makes it
+    from the stored double-double P (k_dP_dd, ensure_dP in plk_engine.hip).  Both orders of the two queries must give the
+    same gradient bit for bit, for the LDS form of K1 (k = 4, 20) and the tiled one (k = 61)."""
+    from phyly_amd import synth
+    w = synth.Workload(cfg)
+    w.setup_engine(eng)
+    eng.set_patterns_codes(w.simulate(S), w.defs)
+    r = w.edge_rates_csr * 1.25
+    eng.update_edge_rates(r)
+    d_first, _ = eng.deriv()                      # K1 with dP
+    eng.update_edge_rates(r * 1.0)                # same values, marks the model dirty again
+    ll, _ = eng.ll()                              # K1 without dP
+    d_after, _ = eng.deriv()                      # dP on demand
+    assert np.all(np.isfinite(ll))
+    assert np.array_equal(d_first, d_after)
+    eng.update_edge_rates(w.edge_rates_csr)
