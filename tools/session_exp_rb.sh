@@ -1,4 +1,4 @@
 set -o pipefail
-root=$(pwd)
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/hess_stats -o run -- python3 $root/tools/time_queries.py --config 3 --sites 100000 --hess-sites 50000 > $root/gpurun_out/hess_prof.log 2>&1
-cd $root; find gpurun_out/hess_stats -name '*kernel_trace.csv' -delete; tail -2 gpurun_out/hess_prof.log
+timeout -k 10 600 python -m pytest tests/test_gpu_fused_asm.py tests/test_gpu_ll.py tests/test_gpu_shard.py tests/test_gpu_fullsize.py tests/test_gpu_group.py -x -q 2>&1 | tail -3 || exit 1
+for c in 3 2; do timeout -k 10 100 python bench.py --config $c --steps 30 --warmup 5 --no-cpu-baseline --deriv-steps 0 2>/dev/null | grep '^{"metric' > gpurun_out/fs_cfg$c.json || exit 1; done
+timeout -k 10 100 python bench.py --sites 1250000 --steps 30 --warmup 5 --no-cpu-baseline --deriv-steps 0 --dist 2>/dev/null | grep '^{"metric' > gpurun_out/fs_proxy.json || exit 1
