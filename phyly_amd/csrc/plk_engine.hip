@@ -2365,9 +2365,21 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     int nsc = 0;
     for (int a = 0; a < N; a++) if (node_int[a] >= 0 && h->scale_node[a]) node_scale[a] = nsc++;
 
+    /* derivative queries without marginals on the edge-at-a-time up pass: nodes whose children are all leaves are finished
+     * inside their parent's visit (their F never goes through HBM), and the up pass rebuilds their L from the tip tables,
+     * so the down pass does not store it either */
+    const bool nodes_wanted = deriv && !marg && (h->opt_up_nodes & 1);
+    std::vector<int> node_inl(N, 0);
+    std::vector<char> skip_l(N, 0);
+    bool any_inl = false;
+    if (deriv && !marg && !nodes_wanted)
+        for (int u = 1; u < N; u++) {
+            const int b = h->preorder[u];
+            if (plk_up_inlinable(h->indptr.data(), edge_tip.data(), b, false)) { node_inl[b] = 1; skip_l[b] = 1; any_inl = true; }
+        }
     /* program of the depth-first down pass (k_down_fused_mfma) */
     PlkChain dch;
-    plk_chain_build(N, h->pg, 2, h->indices.data(), node_int.data(), edge_int.data(), node_scale.data(), dch);
+    plk_chain_build(N, h->pg, 2, h->indices.data(), node_int.data(), edge_int.data(), node_scale.data(), dch, any_inl ? skip_l.data() : nullptr);
     {
         const std::string bad = plk_chain_check(N, h->pg, dch, 2, INT_MAX, nin, nie, nsc, MF_SITES, (size_t)h->obs_nodes.size() * MF_SITES);
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }
@@ -2401,6 +2413,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
     const size_t o_has = put(hd.data(), (size_t)N);
     const size_t o_em = edge_mask ? put(edge_mask, (size_t)E) : 0, o_nm = node_mask ? put(node_mask, (size_t)N) : 0;
     const size_t o_vis = nodes ? put(un.rec.data(), un.rec.size()) : 0;
+    const size_t o_inl = any_inl ? put(node_inl.data(), (size_t)N) : 0;
     const size_t nfr = (size_t)C * E * T * kk4 * 64, ntab = (size_t)C * (ntips + 1) * h->nchar * 4 * R;
     if ((rc = dev_reserve(h, &h->d_u4pack, &h->u4pack_cap, pack.size() + 4)) ||
         (rc = dev_reserve(h, &h->d_u4tip, &h->u4tip_cap, 2 * ntab + rwd.size())) ||
@@ -2472,6 +2485,7 @@ static int run_updown_mfma(plk_engine *h, bool deriv, bool marg, const int *edge
         if (marg) HIPCHK(h, hipMemsetAsync(a.MV, 0, (msum_only ? (size_t)N * k * nwv : (size_t)N * k * n) * sizeof(double), h->stream));
         const size_t lds = (size_t)T * kk4 * 64 * sizeof(double);
         a.visits = nodes ? pk + o_vis : nullptr; a.nvisits = un.nvisits;
+        a.node_inline = any_inl ? pk + o_inl : nullptr;
         const bool nv = nodes && (s0 % MF_SITES) == 0;       /* chunks start at multiples of the site tile */
         if (T == 1) launch_updown_mfma<1>(h, a, pg, grid, lds, deriv, marg, nv);
         else if (T == 2) launch_updown_mfma<2>(h, a, pg, grid, lds, deriv, marg, nv);

@@ -44,6 +44,9 @@ struct MUpArgs {
     /* node-visit up pass (k_up_nodes_mfma): records of plk_up_nodes_build(), and fragD holds the fragments of M^T */
     const int *visits;
     int nvisits;
+    /* k_up_mfma, derivative queries without marginals: node_inline[b] != 0 for a non-root node whose one or two children are
+     * all leaves -- finished inside its parent's visit while F_b is in registers (F_b and L_b never go through HBM) */
+    const int *node_inline;
 };
 
 template <int R>
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
             const int code = ox & 0xff;
             if (code == OP_MATVEC) {
                 const int oz = ops[4 * pc + 2], ow = ops[4 * pc + 3];
-                if (STORE_L) mf_store<R>(a.LN + ((size_t)oz * a.C + c) * R * a.stride, a.stride, lin, x);   /* the node-visit up pass reads edge vectors only */
+                if (STORE_L && oz >= 0) mf_store<R>(a.LN + ((size_t)oz * a.C + c) * R * a.stride, a.stride, lin, x);   /* the node-visit up pass reads edge vectors only; oz < 0: a node the up pass finishes inline (it rebuilds L from the tip tables) */
                 mf_stage(lds_frag, a.fragP + ((size_t)c * a.E + oy) * nfrag, nfrag, tid);
                 double m[R], x0;
                 mf_matvec<T>(lds_frag, a.kk4, lane, x, m);
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
         const int nd = as_uniform(a.preorder)[u];
         const int start = as_uniform(a.indptr)[nd], stop = as_uniform(a.indptr)[nd + 1];
         if (start == stop) continue;
+        if (DERIV && !MARG && a.node_inline && u > 0 && as_uniform(a.node_inline)[nd]) continue;     /* finished inside its parent's visit */
         const bool has = as_uniform(a.node_has_data)[nd];
         const int chn = has ? a.codes[(size_t)nd * a.Spad + sg] : 0;
         const int slot = as_uniform(a.node_scale)[nd];
@@ -434,6 +438,17 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
             const bool want_f = !b_leaf || want_m;
             if (!want_d && !want_f) continue;
             const int chb = b_leaf ? a.codes[(size_t)b * a.Spad + sg] : 0;
+            /* inline child: its one or two leaves (CSR edges bs, bs + 1), their codes, the child's own observation and rescaling slot */
+            const bool inl = DERIV && !MARG && !b_leaf && a.node_inline && as_uniform(a.node_inline)[b];
+            const int bs = inl ? as_uniform(a.indptr)[b] : 0, bn2 = inl && as_uniform(a.indptr)[b + 1] - bs == 2;
+            const int l0 = inl ? as_uniform(a.indices)[bs] : 0, l1 = bn2 ? as_uniform(a.indices)[bs + 1] : 0;
+            const int t0 = inl ? as_uniform(a.edge_tip)[bs] : 0, t1 = bn2 ? as_uniform(a.edge_tip)[bs + 1] : 0;
+            const int cl0 = inl ? a.codes[(size_t)l0 * a.Spad + sg] : 0, cl1 = bn2 ? a.codes[(size_t)l1 * a.Spad + sg] : 0;
+            const bool bhas = inl && as_uniform(a.node_has_data)[b];
+            const int cbn = bhas ? a.codes[(size_t)b * a.Spad + sg] : 0;
+            const int bslot = inl ? as_uniform(a.node_scale)[b] : -1;
+            const bool wl0 = inl && (!a.edge_mask || as_uniform(a.edge_mask)[bs]), wl1 = bn2 && (!a.edge_mask || as_uniform(a.edge_mask)[bs + 1]);
+            double dl0 = 0.0, dl1 = 0.0;
             double dsum = 0.0;
             double macc[R];
 #pragma unroll
@@ -472,7 +487,28 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                         mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, as_uniform(a.edge_tip)[idx], chb, g, y);
                     } else {
                         double x[R], x0;
-                        mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                        if (!inl) mf_load<R>(a.LN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, x);
+                        else {
+                            /* L_b rebuilt in the order the down pass multiplied it: leaf rows, own observation, rescaling factor */
+                            mf_gather<R>(tipc, a.nchar, t0, cl0, g, x);
+                            if (bn2) {
+                                double m2[R];
+                                mf_gather<R>(tipc, a.nchar, t1, cl1, g, m2);
+#pragma unroll
+                                for (int r = 0; r < R; r++) x[r] *= m2[r];
+                            }
+                            if (bhas) {
+                                double m2[R];
+                                mf_gather<R>(tipc, a.nchar, a.ntips, cbn, g, m2);
+#pragma unroll
+                                for (int r = 0; r < R; r++) x[r] *= m2[r];
+                            }
+                            if (bslot >= 0) {
+                                const double sb = a.SC[((size_t)bslot * a.C + c) * n + slc];
+#pragma unroll
+                                for (int r = 0; r < R; r++) x[r] *= sb;
+                            }
+                        }
                         mf_stage(lds_frag, a.fragD + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                         mf_matvec<T>(lds_frag, a.kk4, lane, x, y);
                         if (a.dzero && mf_is_const<R>(x, g, a.k, x0)) {
@@ -491,7 +527,51 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                     double fb[R];
                     mf_stage(lds_frag, a.fragPT + ((size_t)c * a.E + idx) * nfrag, nfrag, tid);
                     mf_matvec<T>(lds_frag, a.kk4, lane, fe, fb);
-                    if (!b_leaf) mf_store<R>(a.FN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, fb);
+                    if (!b_leaf && !inl) mf_store<R>(a.FN + ((size_t)as_uniform(a.node_int)[b] * a.C + c) * R * a.stride, a.stride, lin, fb);
+                    if (inl && (wl0 || wl1)) {
+                        /* the child's leaf edges, while its forward vector is in registers: fb o B_b x s_b, then per leaf the
+                         * edge-form tip row times the other leaf's message (what b's own visit would have computed) */
+                        if (bhas) {
+                            double m2[R];
+                            mf_gather<R>(tipc, a.nchar, a.ntips, cbn, g, m2);
+#pragma unroll
+                            for (int r = 0; r < R; r++) fb[r] *= m2[r];
+                        }
+                        if (bslot >= 0) {
+                            const double sb = a.SC[((size_t)bslot * a.C + c) * n + slc];
+#pragma unroll
+                            for (int r = 0; r < R; r++) fb[r] *= sb;
+                        }
+                        if (wl0) {
+                            double y2[R];
+                            mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, t0, cl0, g, y2);
+                            if (bn2) {
+                                double m2[R];
+                                mf_gather<R>(tipc, a.nchar, t1, cl1, g, m2);
+#pragma unroll
+                                for (int r = 0; r < R; r++) y2[r] *= m2[r];
+                            }
+                            double d2 = 0.0;
+#pragma unroll
+                            for (int r = 0; r < R; r++) d2 = fma(fb[r], y2[r], d2);
+                            d2 += __shfl_xor(d2, 16, 64);
+                            d2 += __shfl_xor(d2, 32, 64);
+                            dl0 = fma(prior, d2, dl0);
+                        }
+                        if (wl1) {
+                            double y2[R], m2[R];
+                            mf_gather<R>(a.dtip + (size_t)c * tabc, a.nchar, t1, cl1, g, y2);
+                            mf_gather<R>(tipc, a.nchar, t0, cl0, g, m2);
+#pragma unroll
+                            for (int r = 0; r < R; r++) y2[r] *= m2[r];
+                            double d2 = 0.0;
+#pragma unroll
+                            for (int r = 0; r < R; r++) d2 = fma(fb[r], y2[r], d2);
+                            d2 += __shfl_xor(d2, 16, 64);
+                            d2 += __shfl_xor(d2, 32, 64);
+                            dl1 = fma(prior, d2, dl1);
+                        }
+                    }
                     if (want_m) {
                         double lb[R];
                         if (b_leaf) mf_gather<R>(tipc, a.nchar, a.ntips, chb, g, lb);
@@ -502,6 +582,8 @@ __global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4))
                 }
             }
             if (want_d && valid && g == 0) a.DV[(size_t)idx * n + sl] = dsum * inv;
+            if (wl0 && valid && g == 0) a.DV[(size_t)bs * n + sl] = dl0 * inv;
+            if (wl1 && valid && g == 0) a.DV[(size_t)(bs + 1) * n + sl] = dl1 * inv;
             if (want_m) MF_OUT_M(b, macc);
         }
     }

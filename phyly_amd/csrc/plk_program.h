@@ -953,7 +953,7 @@ static inline void plk_chain_build(int N, const PlkProgram &pg, int mode, const 
         } else if (code == OP_MATVEC && mode >= 1) {
             o.y = pg.op_edge[pc];
             o.z = node_int ? node_int[indices[o.y]] : 0;
-            if ((mode == 3 || mode == 1) && skip_store && skip_store[indices[o.y]]) o.z = -1;      /* this child's vector is not stored */
+            if (mode >= 1 && skip_store && skip_store[indices[o.y]]) o.z = -1;      /* this child's vector is not stored */
             if (mode == 2) o.w = edge_int[o.y];
         } else if (code == OP_SCALE && mode >= 1 && node_scale) {
             o.y = node_scale[pg.ops[pc].y];
@@ -1368,7 +1368,7 @@ static inline std::string plk_chain_check(int N, const PlkProgram &pg, const Plk
             do { nx = nx + 1 < nops ? nx + 1 : 0; } while ((pg.ops[nx].x & 0xff) != OP_MATVEC);
             if (o.z != nx) return plk_fmt("down program: op %ld names the wrong next product", pc);
         } else if (code == OP_MATVEC && mode >= 1) {
-            if (o.y != pg.op_edge[pc] || o.z < ((mode == 3 || mode == 1) && nint_nodes > 0 ? -1 : 0) || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
+            if (o.y != pg.op_edge[pc] || o.z < (mode >= 1 && nint_nodes > 0 ? -1 : 0) || o.z >= (nint_nodes > 0 ? nint_nodes : nops)) return plk_fmt("down program: op %ld stores to a bad node index", pc);
             if (mode == 2 && (o.w < 0 || o.w >= nint_edges)) return plk_fmt("down program: op %ld stores to a bad edge index", pc);
         } else if (code == OP_PUSH || code == OP_POPMUL) {
             if (o.y < 0 || o.y >= D) return "down program: stack slot out of range";
