@@ -665,6 +665,43 @@ __device__ static inline v4 u4n_child_L(const Up4Args &a, int c, int fl, int bi,
     return v4{m[0].a * m[1].a, m[0].b * m[1].b, m[0].c * m[1].c, m[0].d * m[1].d};
 }
 
+/* The table rows a child's message needs depend on the site's pattern codes only, not on the category: they are looked up
+ * once per visit (row offsets, in doubles) and used by every category.
+ *   leaf: r0 = 4 x code;  pair child: r0 = 4 x combined code;  rebuilt child: r0, r1 = the rows of its two items;  stored child: unused */
+struct U4nRows { unsigned r0, r1; };
+__device__ static inline unsigned u4n_pair_row(const Up4Args &a, int b, unsigned us)
+{
+    const int e0 = as_uniform(a.indptr)[b];
+    const int b0 = as_uniform(a.indices)[e0], b1 = as_uniform(a.indices)[e0 + 1];
+    return 4u * ((unsigned)at_u(a.codes + (size_t)b0 * a.Spad + a.s0, us) * (unsigned)a.nchar + (unsigned)at_u(a.codes + (size_t)b1 * a.Spad + a.s0, us));
+}
+__device__ static inline U4nRows u4n_child_rows(const Up4Args &a, int b, int t, int fl, int bi, unsigned us)
+{
+    U4nRows r = {0u, 0u};
+    if (t >= 0) r.r0 = 4u * at_u(a.codes + (size_t)b * a.Spad + a.s0, us);
+    else if (t < -1) r.r0 = u4n_pair_row(a, b, us);
+    else if (fl & PLK_UN_REBUILD) {
+        const PLK_AS4 int *rt = as_uniform(a.rebuild) + 4 * bi;
+        r.r0 = rt[0] >= 0 ? 4u * at_u(a.codes + (size_t)rt[1] * a.Spad + a.s0, us) : u4n_pair_row(a, rt[1], us);
+        r.r1 = rt[2] >= 0 ? 4u * at_u(a.codes + (size_t)rt[3] * a.Spad + a.s0, us) : u4n_pair_row(a, rt[3], us);
+    }
+    return r;
+}
+/* one item of a rebuilt vector / a pair child's message for category c: tip-table row (t >= 0) or pair-table row (t <= -2) */
+__device__ static inline v4 u4n_row(const Up4Args &a, int c, int t, unsigned row, size_t tabc)
+{
+    if (t >= 0) return ld4u(a.tip + (size_t)c * tabc + (size_t)t * a.nchar * 4, row);
+    return ld4u(a.ptab + ((size_t)c * a.npairs + (-2 - t)) * a.nchar * a.nchar * 4, row);
+}
+/* L_b of an internal child that is not a pair node: stored, or the product of its two items' rows */
+__device__ static inline v4 u4n_child_L_rows(const Up4Args &a, int c, int fl, int bi, const U4nRows &rows, size_t tabc, unsigned us4, size_t n)
+{
+    if (!(fl & PLK_UN_REBUILD)) return ld4u(a.LN + ((size_t)bi * a.C + c) * n * 4, us4);
+    const PLK_AS4 int *rt = as_uniform(a.rebuild) + 4 * bi;
+    const v4 m0 = u4n_row(a, c, rt[0], rows.r0, tabc), m1 = u4n_row(a, c, rt[2], rows.r1, tabc);
+    return v4{m0.a * m1.a, m0.b * m1.b, m0.c * m1.c, m0.d * m1.d};
+}
+
 template <int CM>
 __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up4_nodes(Up4Args a)
 {
@@ -704,9 +741,11 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (deg <= 2) {
             double d_own = 0.0, d0 = 0.0, d1 = 0.0;
             const int fl0 = ch[2], fl1 = deg == 2 ? ch[6] : 0;
-            /* pattern codes of leaf children, once per visit */
-            const unsigned cd0 = ch[1] >= 0 ? 4u * at_u(a.codes + (size_t)ch[0] * a.Spad + a.s0, us) : 0u;
-            const unsigned cd1 = deg == 2 && ch[5] >= 0 ? 4u * at_u(a.codes + (size_t)ch[4] * a.Spad + a.s0, us) : 0u;
+            /* table rows of the children (pattern codes of leaves, combined codes of pair nodes, the items of rebuilt
+             * vectors), once per visit */
+            const U4nRows rw0 = u4n_child_rows(a, ch[0], ch[1], fl0, ch[3], us);
+            const U4nRows rw1 = deg == 2 ? u4n_child_rows(a, ch[4], ch[5], fl1, ch[7], us) : U4nRows{0u, 0u};
+            const unsigned cd0 = rw0.r0, cd1 = rw1.r0;
 #pragma unroll
             for (int c = 0; c < CM; c++) {
                 if (c >= a.C) break;
@@ -716,17 +755,17 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 const double sc = slot >= 0 ? at_u(a.SC + ((size_t)slot * a.C + c) * n, us) : 1.0;
                 v4 m0, m1 = one, ob = one;
                 if (ch[1] >= 0) m0 = ld4u(tipc + (size_t)ch[1] * a.nchar * 4, cd0);
-                else if (ch[1] < -1) m0 = u4n_pair_message(a, c, -2 - ch[1], ch[0], us);
+                else if (ch[1] < -1) m0 = u4n_row(a, c, ch[1], rw0.r0, tabc);
                 else {
-                    const v4 x = u4n_child_L(a, c, fl0, ch[3], tabc, us, us4, n);
+                    const v4 x = u4n_child_L_rows(a, c, fl0, ch[3], rw0, tabc, us4, n);
                     m0 = mv4(Pm + ((size_t)c * a.E + e0 + (fl0 >> PLK_UN_POS_SHIFT)) * 16, x);
                     if (const4(x)) m0 = x;
                 }
                 if (deg == 2) {
                     if (ch[5] >= 0) m1 = ld4u(tipc + (size_t)ch[5] * a.nchar * 4, cd1);
-                    else if (ch[5] < -1) m1 = u4n_pair_message(a, c, -2 - ch[5], ch[4], us);
+                    else if (ch[5] < -1) m1 = u4n_row(a, c, ch[5], rw1.r0, tabc);
                     else {
-                        const v4 x = u4n_child_L(a, c, fl1, ch[7], tabc, us, us4, n);
+                        const v4 x = u4n_child_L_rows(a, c, fl1, ch[7], rw1, tabc, us4, n);
                         m1 = mv4(Pm + ((size_t)c * a.E + e0 + (fl1 >> PLK_UN_POS_SHIFT)) * 16, x);
                         if (const4(x)) m1 = x;
                     }
