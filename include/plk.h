@@ -241,6 +241,8 @@ enum { PLK_OPT_FORCE_GENERIC = 0, PLK_OPT_SITE_CHUNK = 1, PLK_OPT_FUSED_SITES_PE
                                bit 1 (2): k = 4 kernels (k_up4_nodes: a third fewer HBM bytes than k_up4);
                                bit 2 (4): k = 4 kernels WITHOUT the table rebuild of nodes whose two children are leaves or
                                two-leaf nodes (by default their vectors do not go through HBM in either pass);
+                               bit 3 (8): k = 4 kernels WITHOUT finishing two-leaf nodes inside their parent's visit (done for models with one
+                               rate category: with four in flight the visit has no registers left for it);
                                bit 0 (1): matrix-core kernels, 21 <= k <= 64 or all of 9 <= k <= 64 under PLK_OPT_MFMA = 2
                                (k_up_nodes_mfma: fewer HBM bytes, same speed as measured in round 2).
                                Marginal queries always take the one-edge-at-a-time passes.  ARBPLF_UP_NODES in the

@@ -2609,7 +2609,7 @@ static int run_updown4(plk_engine *h, bool deriv, bool marg, const int *edge_mas
         if (h->node_has_data.size() != (size_t)N) h->node_has_data.assign(N, 1);
         plk_up_nodes_build(N, h->indptr.data(), h->indices.data(), h->preorder.data(), h->node_has_data.data(), edge_tip.data(),
                            node_int.data(), node_scale.data(), edge_mask, un4, npairs4 ? pair_of.data() : nullptr,
-                           any_rebuild ? rebuild_n.data() : nullptr);
+                           any_rebuild ? rebuild_n.data() : nullptr, npairs4 > 0 && C == 1 && !(h->opt_up_nodes & 8));
         const std::string bad = plk_up_nodes_check(N, E, h->indptr.data(), h->indices.data(), un4, nin, ntips, nsc, npairs4, edge_tip.data(),
                                                    any_rebuild ? rebuild_tab.data() : nullptr, pair_of.data());
         if (!bad.empty()) { h->err = "internal: " + bad; return PLK_E_ARG; }

@@ -1167,7 +1167,10 @@ static inline std::string plk_up_visits_check(int N, int E, const PlkUpVisits &u
  *                    storage index (internal child) or -1
  */
 enum { PLK_UN_OWN_D = 1, PLK_UN_FROM_REGS = 2 };                                              /* header flags */
-enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_WORK = 7, PLK_UN_PAIR = 8, PLK_UN_REBUILD = 16, PLK_UN_POS_SHIFT = 5 };   /* child flags;
+enum { PLK_UN_LEAF_D = 1, PLK_UN_STORE_G = 2, PLK_UN_CONTINUE = 4, PLK_UN_PAIR = 8, PLK_UN_REBUILD = 16,
+       PLK_UN_INL_OWN = 32, PLK_UN_INL_L0 = 64, PLK_UN_INL_L1 = 128, PLK_UN_INL = 224, PLK_UN_WORK = 7 | 224, PLK_UN_POS_SHIFT = 8 };   /* child flags;
+   PLK_UN_INL_*: a pair child that is FINISHED INSIDE this visit (it gets no visit of its own and its G is neither stored nor
+   handed on): the derivative of the edge into it (OWN) and of its first / second leaf edge (L0 / L1) are wanted;
    PLK_UN_PAIR: the child's message P_b L_b comes from pair table number `fifth field` (its two leaves' codes), L_b is not stored;
    the record's fourth int then still holds the storage index (the child's own visit needs its G);
    PLK_UN_REBUILD: L_b is not stored either: b has two children, each a leaf or a pair node, and L_b is the product of their
@@ -1213,7 +1216,8 @@ static inline void plk_up_rebuild_table(int N, const int *ip, const int *ix, con
  * rebuild: null, or N chars of plk_up_rebuild_table: such a child's flags carry PLK_UN_REBUILD. */
 static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const int *preorder, const char *node_has_data,
                                       const int *edge_tip, const int *node_int, const int *node_scale, const int *edge_mask,
-                                      PlkUpNodes &un, const int *pair_of = nullptr, const char *rebuild = nullptr)
+                                      PlkUpNodes &un, const int *pair_of = nullptr, const char *rebuild = nullptr,
+                                      bool inline_pairs = false)
 {
     un.rec.clear(); un.nvisits = 0;
     std::vector<int> edge_into(N, -1);
@@ -1238,9 +1242,12 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
         from_regs = -1;
         const int hdr[8] = {a, deg, node_int[a], node_scale[a], node_has_data[a] ? 1 : 0, start, ea, hfl};
         un.rec.insert(un.rec.end(), hdr, hdr + 8);
+        /* inline_pairs: a pair child (two leaves, no data) is finished inside this visit: its G is used while it is in
+         * registers, never stored, and the node gets no visit */
+        auto inl = [&](int j) { return inline_pairs && deg <= 2 && pair_of && edge_tip[start + j] < 0 && pair_of[ix[start + j]] >= 0; };      /* (the kernel's path for more than two children has no inline form) */
         /* the child that continues in registers: the last internal child with work; its record goes last */
         int cont = -1;
-        if (below[a]) for (int j = 0; j < deg; j++) if (edge_tip[start + j] < 0 && sub[ix[start + j]]) cont = j;
+        if (below[a]) for (int j = 0; j < deg; j++) if (edge_tip[start + j] < 0 && sub[ix[start + j]] && !inl(j)) cont = j;
         for (int pass = 0; pass < 2; pass++)
             for (int j = 0; j < deg; j++) {
                 if ((j == cont) != (pass == 1)) continue;
@@ -1249,6 +1256,7 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
                 int fl = 0;
                 if (below[a]) {
                     if (leaf) fl = wanted(idx) ? PLK_UN_LEAF_D : 0;
+                    else if (inl(j)) fl = (wanted(idx) ? PLK_UN_INL_OWN : 0) | (wanted(ip[b]) ? PLK_UN_INL_L0 : 0) | (wanted(ip[b] + 1) ? PLK_UN_INL_L1 : 0);
                     else if (sub[b]) fl = j == cont ? PLK_UN_CONTINUE : PLK_UN_STORE_G;
                 }
                 const bool pr = !leaf && pair_of && pair_of[b] >= 0;
@@ -1258,7 +1266,7 @@ static inline void plk_up_nodes_build(int N, const int *ip, const int *ix, const
             }
         un.nvisits++;
         /* stored children are visited later (depth first: the most recently stored first), the continued one next */
-        for (int j = 0; j < deg; j++) if (j != cont && edge_tip[start + j] < 0 && below[a] && sub[ix[start + j]]) stack.push_back(ix[start + j]);
+        for (int j = 0; j < deg; j++) if (j != cont && edge_tip[start + j] < 0 && below[a] && sub[ix[start + j]] && !inl(j)) stack.push_back(ix[start + j]);
         if (cont >= 0) from_regs = ix[start + cont];
     }
 }
@@ -1294,6 +1302,12 @@ static inline std::string plk_up_nodes_check(int N, int E, const int *ip, const 
             int t = ch[4 * j + 1];
             if (pos < 0 || pos >= deg || seen[pos]) return plk_fmt("up nodes: child positions of visit %ld", v);
             seen[pos] = 1;
+            if (fl & PLK_UN_INL) {
+                /* finished inside this visit: a pair child with nothing stored or handed on, never visited itself */
+                if (!(fl & PLK_UN_PAIR) || (fl & (PLK_UN_STORE_G | PLK_UN_CONTINUE | PLK_UN_LEAF_D)) || b < 0 || b >= N) return plk_fmt("up nodes: flags of an inline pair child in visit %ld", v);
+                if (visited[b]) return plk_fmt("up nodes: inline pair child %ld is also visited", b);
+                visited[b] = 1;
+            }
             if (fl & PLK_UN_PAIR) {
                 /* the message of this child is a pair-table row: two leaf children, table index in range */
                 const int pi = -2 - t;

@@ -746,6 +746,35 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
             const U4nRows rw0 = u4n_child_rows(a, ch[0], ch[1], fl0, ch[3], us);
             const U4nRows rw1 = deg == 2 ? u4n_child_rows(a, ch[4], ch[5], fl1, ch[7], us) : U4nRows{0u, 0u};
             const unsigned cd0 = rw0.r0, cd1 = rw1.r0;
+            /* pair children finished inside this visit (PLK_UN_INL_*): CSR edge of their first leaf, tip slots and code rows of
+             * their two leaves, derivative accumulators (edge into the child, first leaf edge, second leaf edge) */
+            /* (one-category instantiation only: with four categories in flight the visit has no registers left for it -- measured
+             * slower --, and the host asks for inline pair children only when C = 1) */
+            const bool in0 = CM == 1 && (fl0 & PLK_UN_INL) != 0, in1 = CM == 1 && (fl1 & PLK_UN_INL) != 0;
+            const int le0 = in0 ? as_uniform(a.indptr)[ch[0]] : 0, le1 = in1 ? as_uniform(a.indptr)[ch[4]] : 0;
+            const int ts00 = in0 ? as_uniform(a.edge_tip)[le0] : 0, ts01 = in0 ? as_uniform(a.edge_tip)[le0 + 1] : 0;
+            const int ts10 = in1 ? as_uniform(a.edge_tip)[le1] : 0, ts11 = in1 ? as_uniform(a.edge_tip)[le1 + 1] : 0;
+            const unsigned cr00 = in0 ? 4u * at_u(a.codes + (size_t)as_uniform(a.indices)[le0] * a.Spad + a.s0, us) : 0u;
+            const unsigned cr01 = in0 ? 4u * at_u(a.codes + (size_t)as_uniform(a.indices)[le0 + 1] * a.Spad + a.s0, us) : 0u;
+            const unsigned cr10 = in1 ? 4u * at_u(a.codes + (size_t)as_uniform(a.indices)[le1] * a.Spad + a.s0, us) : 0u;
+            const unsigned cr11 = in1 ? 4u * at_u(a.codes + (size_t)as_uniform(a.indices)[le1 + 1] * a.Spad + a.s0, us) : 0u;
+            double di0[3] = {0.0, 0.0, 0.0}, di1[3] = {0.0, 0.0, 0.0};
+            /* what the pair child's own visit would compute from its G (here G_) for category c: both its children are leaves,
+             * it has no data and no rescaling (the same operations in the same order: the same bits) */
+#define U4N_INLINE_PAIR(FL_, G_, EDGE_, TS0_, TS1_, CR0_, CR1_, LE_, D_)                                            \
+            do { const v4 t0_ = ld4u(tipc + (size_t)(TS0_) * a.nchar * 4, CR0_), t1_ = ld4u(tipc + (size_t)(TS1_) * a.nchar * 4, CR1_); \
+                 if ((FL_) & PLK_UN_INL_OWN) {                                                                      \
+                     const v4 z_ = mtv4(Mm + ((size_t)c * a.E + (EDGE_)) * 16, G_);                                 \
+                     const v4 l_ = mul4(mul4(t0_, t1_), one);                                                        \
+                     const double d_ = (a.dzero && const4(l_)) ? 0.0 : fma(z_.d, l_.d, fma(z_.c, l_.c, fma(z_.b, l_.b, z_.a * l_.a))); \
+                     D_[0] = fma(pcw[c] * 1.0, d_, D_[0]); }                                                         \
+                 v4 f_ = mtv4(Pm + ((size_t)c * a.E + (EDGE_)) * 16, G_);                                           \
+                 f_ = mul4(f_, one);                                                                                 \
+                 f_.a *= 1.0; f_.b *= 1.0; f_.c *= 1.0; f_.d *= 1.0;                                                 \
+                 if ((FL_) & PLK_UN_INL_L0) { const v4 y_ = ld4u(dtipc + (size_t)(TS0_) * a.nchar * 4, CR0_); const v4 q_ = mul4(f_, t1_); \
+                     D_[1] = fma(pcw[c], fma(q_.d, y_.d, fma(q_.c, y_.c, fma(q_.b, y_.b, q_.a * y_.a))), D_[1]); }   \
+                 if ((FL_) & PLK_UN_INL_L1) { const v4 y_ = ld4u(dtipc + (size_t)(TS1_) * a.nchar * 4, CR1_); const v4 q_ = mul4(f_, t0_); \
+                     D_[2] = fma(pcw[c], fma(q_.d, y_.d, fma(q_.c, y_.c, fma(q_.b, y_.b, q_.a * y_.a))), D_[2]); } } while (0)
 #pragma unroll
             for (int c = 0; c < CM; c++) {
                 if (c >= a.C) break;
@@ -789,6 +818,8 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     const v4 y = ld4u(dtipc + (size_t)ch[5] * a.nchar * 4, cd1);
                     d1 = fma(pcw[c], fma(g1.d, y.d, fma(g1.c, y.c, fma(g1.b, y.b, g1.a * y.a))), d1);
                 } else if ((fl1 & PLK_UN_STORE_G) && valid) st4u(a.FN + ((size_t)ch[7] * a.C + c) * n * 4, us4, g1);
+                if (CM == 1 && in0) U4N_INLINE_PAIR(fl0, g0, e0 + (fl0 >> PLK_UN_POS_SHIFT), ts00, ts01, cr00, cr01, le0, di0);
+                if (CM == 1 && in1) U4N_INLINE_PAIR(fl1, g1, e0 + (fl1 >> PLK_UN_POS_SHIFT), ts10, ts11, cr10, cr11, le1, di1);
                 /* the continued child is the last record: record 1 of two, record 0 of one */
                 gc[c] = deg == 2 ? g1 : g0;
             }
@@ -796,7 +827,14 @@ __global__ __launch_bounds__(UD4_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (hfl & PLK_UN_OWN_D) { double *dp = a.DV + (size_t)ea * n; asm volatile("" : "+s"(dp)); dp[us] = d_own * inv; }
                 if (fl0 & PLK_UN_LEAF_D) { double *dp = a.DV + (size_t)(e0 + (fl0 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = d0 * inv; }
                 if (fl1 & PLK_UN_LEAF_D) { double *dp = a.DV + (size_t)(e0 + (fl1 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = d1 * inv; }
+                if (CM == 1 && (fl0 & PLK_UN_INL_OWN)) { double *dp = a.DV + (size_t)(e0 + (fl0 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = di0[0] * inv; }
+                if (CM == 1 && (fl0 & PLK_UN_INL_L0)) { double *dp = a.DV + (size_t)le0 * n; asm volatile("" : "+s"(dp)); dp[us] = di0[1] * inv; }
+                if (CM == 1 && (fl0 & PLK_UN_INL_L1)) { double *dp = a.DV + (size_t)(le0 + 1) * n; asm volatile("" : "+s"(dp)); dp[us] = di0[2] * inv; }
+                if (CM == 1 && (fl1 & PLK_UN_INL_OWN)) { double *dp = a.DV + (size_t)(e0 + (fl1 >> PLK_UN_POS_SHIFT)) * n; asm volatile("" : "+s"(dp)); dp[us] = di1[0] * inv; }
+                if (CM == 1 && (fl1 & PLK_UN_INL_L0)) { double *dp = a.DV + (size_t)le1 * n; asm volatile("" : "+s"(dp)); dp[us] = di1[1] * inv; }
+                if (CM == 1 && (fl1 & PLK_UN_INL_L1)) { double *dp = a.DV + (size_t)(le1 + 1) * n; asm volatile("" : "+s"(dp)); dp[us] = di1[2] * inv; }
             }
+#undef U4N_INLINE_PAIR
         } else {
             /* more than two children: messages recomputed per child (as the one-edge-at-a-time pass does); one child at
              * a time over all categories, so that its derivative is still written once */

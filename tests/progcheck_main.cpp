@@ -187,6 +187,36 @@ static std::string check_tree(const Tree &t, const std::vector<char> &has, int n
                            pair_of.data(), rb.data());
         bad = plk_up_nodes_check(N, E, t.ip.data(), t.ix.data(), un, nin, ntips, nsc, npairs, edge_tip.data(), rtab.data(), pair_of.data());
         if (!bad.empty()) return "up nodes (pairs, rebuilt children): " + bad;
+        /* pair children finished inside their parent's visit, without and with an edge mask: every wanted edge still exactly once */
+        {
+            std::vector<int> emask(E);
+            unsigned lcg2 = 4242u + (unsigned)N * 17u;
+            for (int e = 0; e < E; e++) { lcg2 = lcg2 * 1664525u + 1013904223u; emask[e] = (lcg2 >> 24) % 3 != 0; }
+            for (int masked = 0; masked < 2; masked++) {
+                PlkUpNodes ui;
+                plk_up_nodes_build(N, t.ip.data(), t.ix.data(), t.pre.data(), has.data(), edge_tip.data(), node_int.data(), node_scale.data(),
+                                   masked ? emask.data() : nullptr, ui, pair_of.data(), rb.data(), true);
+                bad = plk_up_nodes_check(N, E, t.ip.data(), t.ix.data(), ui, nin, ntips, nsc, npairs, edge_tip.data(), rtab.data(), pair_of.data());
+                if (!bad.empty()) return "up nodes (inline pair children): " + bad;
+                std::vector<int> done(E, 0);
+                size_t vq = 0;
+                for (int v = 0; v < ui.nvisits; v++) {
+                    const int *h = &ui.rec[vq];
+                    if ((h[7] & PLK_UN_OWN_D) && h[6] >= 0) done[h[6]]++;
+                    for (int j = 0; j < h[1]; j++) {
+                        const int fl = h[8 + 4 * j + 2], b = h[8 + 4 * j];
+                        if (fl & PLK_UN_LEAF_D) done[h[5] + (fl >> PLK_UN_POS_SHIFT)]++;
+                        if (fl & PLK_UN_INL_OWN) done[h[5] + (fl >> PLK_UN_POS_SHIFT)]++;
+                        if (fl & PLK_UN_INL_L0) done[t.ip[b]]++;
+                        if (fl & PLK_UN_INL_L1) done[t.ip[b] + 1]++;
+                        if ((fl & PLK_UN_INL) && h[1] > 2) return "up nodes: inline pair child under a node with more than two children";
+                    }
+                    vq += 8 + 4 * (size_t)h[1];
+                }
+                for (int e = 0; e < E; e++)
+                    if (done[e] != ((!masked || emask[e]) ? 1 : 0)) return "up nodes (inline pairs): edge " + std::to_string(e) + " finished " + std::to_string(done[e]) + " times";
+            }
+        }
         int nflag = 0, nrb = 0;
         size_t vp = 0;
         for (int v = 0; v < un.nvisits; v++) {
