@@ -241,6 +241,47 @@ __global__ __launch_bounds__(UDV_BLOCK) void k_down_vec(UpVecArgs a, const int *
  * (the host builder plk_up_visits_build() and this kernel are the two halves of that contract; the stream always has one
  * spare matrix at the end for the look-ahead)
  */
+/* Sums over the wave's 64 lanes of K per-lane values (the K states of a node's weighted marginal term), through a
+ * wave-private LDS strip instead of K butterfly reductions (K x 18 data-parallel-primitive instructions: a third of the
+ * marginal pass at K = 20).  Two halves of H = K / 2 states: every lane writes its H values as rows [state][lane] (row
+ * stride 65: the column reads below spread over the banks), then lane (q = lane / 16, s = lane % 16 < H) adds the 16
+ * values of state s that lanes 16 q .. 16 q + 15 wrote, in lane order, and two exchanges add the four quarters.
+ * Returns, in lanes with q < 2 and s < H, the total of state q * H + s (udv_sum_state() names it); fixed order, no atomics. */
+#define UDV_SUM_STRIP(K_) (((K_) / 2) * 65)
+template <int K>
+__device__ __forceinline__ double udv_state_sums(const double (&v)[K], double *strip, int lane)
+{
+    constexpr int H = K / 2;
+    static_assert(K % 2 == 0 && H <= 16, "state sums: K");
+    const int q = lane >> 4, s = lane & 15;
+    double res[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    /* the strip's previous reads are done (same wave: in order) */
+#pragma unroll
+        for (int i = 0; i < H; i++) strip[i * 65 + lane] = v[h * H + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double acc = 0.0;
+        const double *col = strip + (s < H ? s : 0) * 65 + q * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc += col[j];
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        res[h] = acc;
+    }
+    return q == 0 ? res[0] : res[1];
+}
+/* the state whose total udv_state_sums() left in this lane, or -1 */
+template <int K>
+__device__ __forceinline__ int udv_sum_state(int lane)
+{
+    const int q = lane >> 4, s = lane & 15;
+    return q < 2 && s < K / 2 ? q * (K / 2) + s : -1;
+}
+
 template <int K, bool DERIV, bool MARG>
 __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_up_vec(UpVecArgs a)
 {
@@ -255,6 +296,9 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     const double inv = 1.0 / a.LH[slc];
     constexpr int KK = K * K;
     const size_t nwv = (size_t)gridDim.x * (UDV_BLOCK / 64), wv = (size_t)blockIdx.x * (UDV_BLOCK / 64) + (threadIdx.x >> 6);
+    __shared__ double sum_strips[MARG ? (UDV_BLOCK / 64) * UDV_SUM_STRIP(K) : 1];      /* site-summed marginals: one strip per wave (udv_state_sums) */
+    double *strip = sum_strips + (MARG ? (threadIdx.x >> 6) * UDV_SUM_STRIP(K) : 0);
+    const int sum_st = udv_sum_state<K>(threadIdx.x & 63);
 
     {   /* root: forward vector = root prior weights; its marginal */
         const int root = vis[0], root_int = vis[2];
@@ -326,11 +370,12 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
 #define UDV_OUT_M(NODE, FB, LB)                                                                           \
             do { if (a.MVS) {      /* site sums only: the wave's weighted sum of this category's term, accumulated per wave */ \
                      const double wi_ = valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv * pc : 0.0;          \
-                     _Pragma("unroll") for (int i = 0; i < K; i++) {                                      \
-                         const double t_ = wave64_sum_lane63(wi_ * FB[i] * LB[i]);                        \
-                         if (i < a.k && (threadIdx.x & 63) == 63) {                                       \
-                             double *mp_ = a.MVS + ((size_t)(NODE) * a.k + i) * nwv + wv;                 \
-                             *mp_ = first_cat ? t_ : *mp_ + t_; } }                                       \
+                     double v_[K];                                                                        \
+                     _Pragma("unroll") for (int i = 0; i < K; i++) v_[i] = wi_ * FB[i] * LB[i];           \
+                     const double t_ = udv_state_sums<K>(v_, strip, threadIdx.x & 63);                   \
+                     if (sum_st >= 0 && sum_st < a.k) {                                                   \
+                         double *mp_ = a.MVS + ((size_t)(NODE) * a.k + sum_st) * nwv + wv;                \
+                         *mp_ = first_cat ? t_ : *mp_ + t_; }                                             \
                  } else if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {         \
                  double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
                  const double t_ = pc * FB[i] * LB[i]; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
@@ -338,12 +383,13 @@ __global__ __launch_bounds__(UDV_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
             /* marginal of a leaf that observes state ST_ at this site: one non-zero entry FS_ = F(ST_) (B = 1 there) */
 #define UDV_OUT_M1(NODE, ST_, FS_)                                                                        \
             do { if (a.MVS) {                                                                             \
-                     const double v_ = (valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv * pc : 0.0) * (FS_);  \
-                     _Pragma("unroll") for (int i = 0; i < K; i++) {                                      \
-                         const double t_ = wave64_sum_lane63((ST_) == i ? v_ : 0.0);                      \
-                         if (i < a.k && (threadIdx.x & 63) == 63) {                                       \
-                             double *mp_ = a.MVS + ((size_t)(NODE) * a.k + i) * nwv + wv;                 \
-                             *mp_ = first_cat ? t_ : *mp_ + t_; } }                                       \
+                     const double x_ = (valid ? (a.wsite ? a.wsite[sl] : 1.0) * inv * pc : 0.0) * (FS_);  \
+                     double v_[K];                                                                        \
+                     _Pragma("unroll") for (int i = 0; i < K; i++) v_[i] = (ST_) == i ? x_ : 0.0;         \
+                     const double t_ = udv_state_sums<K>(v_, strip, threadIdx.x & 63);                   \
+                     if (sum_st >= 0 && sum_st < a.k) {                                                   \
+                         double *mp_ = a.MVS + ((size_t)(NODE) * a.k + sum_st) * nwv + wv;                \
+                         *mp_ = first_cat ? t_ : *mp_ + t_; }                                             \
                  } else if (valid) { _Pragma("unroll") for (int i = 0; i < K; i++) if (i < a.k) {         \
                  double *mp_ = a.MV + ((size_t)(NODE) * a.k + i) * n + sl;                                \
                  const double t_ = (ST_) == i ? pc * (FS_) : 0.0; *mp_ = (first_cat ? t_ : *mp_ + t_) * (last_cat ? inv : 1.0); } } } while (0)
