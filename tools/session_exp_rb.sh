@@ -1,4 +1,4 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_deriv_marginal.py tests/test_gpu_differential.py tests/test_gpu_shard.py tests/test_gpu_golden.py -x -q 2>&1 | tail -4 || exit 1
-python3 tools/time_queries.py --config 4 2>/dev/null | grep '^{' | cut -c1-300
-python3 tools/time_queries.py --config 4 2>/dev/null | grep '^{' | cut -c1-300
+tools/profile_r03.sh 4 || exit 1
+: > gpurun_out/r03/query_times.jsonl
+for c in 2 3 4 5; do hs=0; [ $c = 2 ] && hs=1000000; [ $c = 3 ] && hs=500000; python3 tools/time_queries.py --config $c --hess-sites $hs 2>/dev/null | grep '^{' >> gpurun_out/r03/query_times.jsonl || exit 1; done
