@@ -1,3 +1,4 @@
-for rep in 1 2; do for o in 1 9; do
-  timeout -k 10 120 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --deriv-steps 0 --engine-option 6=$o 2>/dev/null | grep '^{"metric' > gpurun_out/wu_${o}_$rep.json || exit 1
-done; done
+set -o pipefail
+timeout -k 10 600 python -m pytest tests/test_gpu_deriv_marginal.py tests/test_gpu_differential.py -x -q 2>&1 | tail -3 || exit 1
+python3 tools/time_queries.py --config 5 2>/dev/null | grep '^{' | cut -c1-300
+python3 tools/time_queries.py --config 5 2>/dev/null | grep '^{' | cut -c1-300
