@@ -115,8 +115,9 @@ def test_deep_scaling_no_underflow(eng, oracle):
 
 @pytest.mark.parametrize("ns", [1, 2])
 def test_fused_assembly_variants(eng, oracle, ns):
-    """both assembly interpreters (one and two sites per lane; 256- and 512-site tiles), ragged sizes, a
-    caterpillar-like tree that needs the 8-slot stack, more than 16 character definitions (unpacked codes)"""
+    """the 256-site-tile interpreters under PLK_OPT_FUSED_SITES_PER_LANE = 1 (the assembly interpreter) and = 2 (the C++
+    interpreter with two sites per lane, 512-site tiles), ragged sizes, a caterpillar-like tree that needs the 8-slot stack,
+    more than 16 character definitions (unpacked codes)"""
     from phyly_amd import synth, engine as E
     eng.set_option(E.OPT_FUSED_NS, ns)
     try:
