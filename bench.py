@@ -195,9 +195,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.dist
     if use_dist:
+        # stdout carries the one JSON line of rank 0 and nothing else: RCCL prints its version banner with printf when
+        # NCCL_DEBUG is set (the GPU boxes export NCCL_DEBUG=VERSION), so file descriptor 1 points at stderr while the
+        # communicators are set up and the steps run, and is put back just before the line is printed
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    def restore_stdout():
+        if use_dist:
+            sys.stdout.flush()
+            os.dup2(saved_stdout_fd, 1)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -479,8 +491,10 @@ def main():
             out["check"] = dict(sites=n, max_rel_err=err, tol=1e-12,
                                 against="oracle (long double build) on the first %d sites of the alignment" % n)
             if not err <= 1e-12:
+                restore_stdout()
                 print(json.dumps(out), flush=True)
                 raise SystemExit("bench.py: GPU per-site ll differs from the CPU checker (max rel err %g)" % err)
+        restore_stdout()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
